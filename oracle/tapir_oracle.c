@@ -1,0 +1,699 @@
+/*
+ * tapir_oracle.c -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product (tapir_amd/) never links, imports or falls back to it.
+ *
+ * What it restates (reference = /root/reference, cited file:line):
+ *   orc_townsend_pi / orc_net_pi     tapir/compute.py:46-48, bin/tapir_compute.py:119 (nansum over sites)
+ *   orc_quad_townsend                scipy.integrate.quad as called at tapir/compute.py:50-52:
+ *                                    QUADPACK dqagse (21-point Gauss-Kronrod, epsabs=epsrel=1.49e-8,
+ *                                    limit=50).  QUADPACK is third-party (netlib, public domain, shipped
+ *                                    inside scipy; reference pins only scipy>=0.9.0, setup.py:27); its
+ *                                    published algorithm (Piessens et al. 1983: dqagse/dqk21/dqelg/dqpsrt)
+ *                                    is restated here and checked against scipy.integrate.quad in tests.
+ *   orc_integral_closed              analytic antiderivative of tapir/compute.py:46-48:
+ *                                    int 16 r^2 t exp(-4 r t) dt = -(4rt+1) exp(-4rt)
+ *   orc_site_rates                   HyPhy stage 2, tapir/data/models_and_rates.bf:978-1070: per column,
+ *                                    maximise over siteRate s>=0 the Felsenstein pruning likelihood of the
+ *                                    fixed tree with every branch length multiplied by s, GTR rate matrix
+ *                                    Q = R o pi (unnormalised, bf:978-1001), start s=1 (bf:1050);
+ *                                    reported rate = s*kappa, subst = rate*chronoLength (bf:1056-1061),
+ *                                    ll = max log L (bf:1066).  HyPhy itself is third-party, not vendored and
+ *                                    not runnable here: the only pin is the known-answer file
+ *                                    tapir/tests/test-hyphy/chr1_918.subsmodel.phydesign.rates (4 dp).
+ *   orc_informative_counts           tapir/compute.py:96-106 (count of A/C/G/T cells per column)
+ *
+ * Optimiser policy (HyPhy's own derivative-free optimiser is not reproducible):
+ *   maximise f(u) = log L(exp(u)) from u=0 (s=1) with a safeguarded Newton iteration that follows the
+ *   uphill direction to the nearest local maximum.  Flags: 0 interior optimum, 1 flat (<=1 resolved
+ *   taxon: L does not depend on s, s stays 1), 2 saturated (still uphill at s = 1e4), 3 optimum at
+ *   s = 0 (all resolved taxa carry the same base), 4 iteration limit.
+ *
+ * State encoding: one byte per cell, bit mask A=1 C=2 G=4 T=8; gap/?/N = 15; IUPAC codes = unions.
+ * Alignment layout: taxon-major, states[taxon*ncols + col].
+ * Tree layout: nodes in post-order (children before parents, root last); parent[root] = -1;
+ *   leaf_taxon[n] = row of the alignment for a leaf, -1 for an internal node; blen[n] = length of the
+ *   branch above node n (ignored for the root), already divided by the correction factor.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define ORC_U_MIN (-23.025850929940457) /* log(1e-10) */
+#define ORC_U_MAX (9.210340371976184)   /* log(1e4)   */
+#define ORC_STEP_MAX 2.0
+#define ORC_STEP_TOL 1e-9
+#define ORC_MAXIT 100
+
+/* ------------------------------------------------------------------------------------------------
+ * PI(t) and its integrals
+ * ---------------------------------------------------------------------------------------------- */
+
+/* tapir/compute.py:46-48, same operation order: ((16*(r*r))*t)*exp(-((4*r)*t)) */
+double orc_townsend_pi(double t, double r) { return 16.0 * (r * r) * t * exp(-(4.0 * r * t)); }
+
+/* bin/tapir_compute.py:114,119: pi = get_townsend_pi(time_vector, rates); nansum(pi, axis=1) */
+void orc_net_pi(const double *rates, int64_t n, int32_t T, double *net_out) {
+    for (int32_t t = 0; t < T; ++t) {
+        double acc = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double v = orc_townsend_pi((double)t, rates[i]);
+            if (!isnan(v)) acc += v;
+        }
+        net_out[t] = acc;
+    }
+}
+
+/* closed form: F(t) = -(4rt+1)exp(-4rt);  integral = F(b)-F(a) = g(4ra)-g(4rb)... written with
+ * g(x) = 1-(1+x)exp(-x) (series for small x) so that tiny rates keep their digits. */
+static double g_small(double x) {
+    if (x < 0.1) { /* g(x) = sum_{k>=2} (-1)^k (k-1) x^k / k!  =  x^2/2 - x^3/3 + x^4/8 - ... */
+        double term = x * x * 0.5, sum = 0.0; /* term = x^k / k! */
+        for (int k = 2; k < 40; ++k) {
+            double add = term * (double)(k - 1);
+            sum += (k & 1) ? -add : add;
+            if (add <= 1e-20 * fabs(sum)) break;
+            term = term * x / (double)(k + 1);
+        }
+        return sum;
+    }
+    return 1.0 - (1.0 + x) * exp(-x);
+}
+double orc_integral_closed(double a, double b, double r) {
+    if (isnan(r)) return NAN;
+    return g_small(4.0 * r * b) - g_small(4.0 * r * a);
+}
+
+/* ---- QUADPACK dqk21: 21-point Gauss-Kronrod rule --------------------------------------------- */
+static const double WG[5] = {0.066671344308688137593568809893332, 0.149451349150580593145776339657697,
+                             0.219086362515982043995534934228163, 0.269266719309996355091226921569469,
+                             0.295524224714752870173815619188769};
+static const double XGK[11] = {0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+                               0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+                               0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+                               0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+                               0.294392862701460198131126603103866, 0.148874338981631210884826001129720,
+                               0.0};
+static const double WGK[11] = {0.011694638867371874278064396062192, 0.032558162307964727478818972459390,
+                               0.054755896574351996031381300244580, 0.075039674810919952767043140916190,
+                               0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+                               0.123491976262065851077958109585166, 0.134709217311473325928054001771707,
+                               0.142775938577060080797094273138717, 0.147739104901338491374841515972068,
+                               0.149445554002916905664936468389821};
+
+static void dqk21(double rate, double a, double b, double *result, double *abserr, double *resabs,
+                  double *resasc) {
+    const double epmach = DBL_EPSILON, uflow = DBL_MIN;
+    double fv1[10], fv2[10];
+    double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    double resg = 0.0, fc = orc_townsend_pi(centr, rate), resk = WGK[10] * fc;
+    *resabs = fabs(resk);
+    for (int j = 0; j < 5; ++j) {
+        int jtw = 2 * j + 1;
+        double absc = hlgth * XGK[jtw];
+        double f1 = orc_townsend_pi(centr - absc, rate), f2 = orc_townsend_pi(centr + absc, rate);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        double fsum = f1 + f2;
+        resg += WG[j] * fsum;
+        resk += WGK[jtw] * fsum;
+        *resabs += WGK[jtw] * (fabs(f1) + fabs(f2));
+    }
+    for (int j = 0; j < 5; ++j) {
+        int jtwm1 = 2 * j;
+        double absc = hlgth * XGK[jtwm1];
+        double f1 = orc_townsend_pi(centr - absc, rate), f2 = orc_townsend_pi(centr + absc, rate);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        double fsum = f1 + f2;
+        resk += WGK[jtwm1] * fsum;
+        *resabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    double reskh = resk * 0.5;
+    *resasc = WGK[10] * fabs(fc - reskh);
+    for (int j = 0; j < 10; ++j) *resasc += WGK[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    *result = resk * hlgth;
+    *resabs *= dhlgth;
+    *resasc *= dhlgth;
+    *abserr = fabs((resk - resg) * hlgth);
+    if (*resasc != 0.0 && *abserr != 0.0) {
+        double q = pow(200.0 * *abserr / *resasc, 1.5);
+        *abserr = *resasc * (q < 1.0 ? q : 1.0);
+    }
+    if (*resabs > uflow / (50.0 * epmach)) {
+        double fl = (epmach * 50.0) * *resabs;
+        if (fl > *abserr) *abserr = fl;
+    }
+}
+
+/* ---- QUADPACK dqpsrt: keep the error list ordered ------------------------------------------- */
+/* 1-based indices as in the published routine; arrays are sized limit+1 and slot 0 is unused. */
+static void dqpsrt(int limit, int last, int *maxerr, double *ermax, const double *elist, int *iord,
+                   int *nrmax) {
+    int i, ibeg, isucc, j, jbnd, jupbn, k;
+    double errmax, errmin;
+    if (last <= 2) {
+        iord[1] = 1; iord[2] = 2;
+        goto done;
+    }
+    errmax = elist[*maxerr];
+    if (*nrmax != 1) {
+        int ido = *nrmax - 1;
+        for (i = 1; i <= ido; ++i) {
+            isucc = iord[*nrmax - 1];
+            if (errmax <= elist[isucc]) break;
+            iord[*nrmax] = isucc;
+            --*nrmax;
+        }
+    }
+    jupbn = last;
+    if (last > (limit / 2 + 2)) jupbn = limit + 3 - last;
+    errmin = elist[last];
+    jbnd = jupbn - 1;
+    ibeg = *nrmax + 1;
+    if (ibeg <= jbnd) {
+        for (i = ibeg; i <= jbnd; ++i) {
+            isucc = iord[i];
+            if (errmax >= elist[isucc]) {
+                /* insert errmin by traversing the list bottom-up */
+                iord[i - 1] = *maxerr;
+                k = jbnd;
+                for (j = i; j <= jbnd; ++j) {
+                    isucc = iord[k];
+                    if (errmin < elist[isucc]) {
+                        iord[k + 1] = last;
+                        goto done;
+                    }
+                    iord[k + 1] = isucc;
+                    --k;
+                }
+                iord[i] = last;
+                goto done;
+            }
+            iord[i - 1] = isucc;
+        }
+    }
+    iord[jbnd] = *maxerr;
+    iord[jupbn] = last;
+done:
+    *maxerr = iord[*nrmax];
+    *ermax = elist[*maxerr];
+}
+
+/* ---- QUADPACK dqelg: epsilon algorithm ------------------------------------------------------- */
+/* epstab is 1-based with 52 usable entries; res3la 1-based with 3 entries. */
+static void dqelg(int *n, double *epstab, double *result, double *abserr, double *res3la, int *nres) {
+    const double epmach = DBL_EPSILON, oflow = DBL_MAX;
+    const int limexp = 50;
+    int i, ib, ib2, ie, indx, k1, k2, k3, newelm, num;
+    double delta1, delta2, delta3, e0, e1, e1abs, e2, e3, epsinf, err1, err2, err3, error, res, ss, tol1,
+        tol2, tol3;
+    ++*nres;
+    *abserr = oflow;
+    *result = epstab[*n];
+    if (*n < 3) goto L100;
+    epstab[*n + 2] = epstab[*n];
+    newelm = (*n - 1) / 2;
+    epstab[*n] = oflow;
+    num = *n;
+    k1 = *n;
+    for (i = 1; i <= newelm; ++i) {
+        k2 = k1 - 1;
+        k3 = k1 - 2;
+        res = epstab[k1 + 2];
+        e0 = epstab[k3];
+        e1 = epstab[k2];
+        e2 = res;
+        e1abs = fabs(e1);
+        delta2 = e2 - e1;
+        err2 = fabs(delta2);
+        tol2 = fmax(fabs(e2), e1abs) * epmach;
+        delta3 = e1 - e0;
+        err3 = fabs(delta3);
+        tol3 = fmax(e1abs, fabs(e0)) * epmach;
+        if (err2 <= tol2 && err3 <= tol3) {
+            /* e0, e1 and e2 are equal to within machine accuracy: convergence is assumed */
+            *result = res;
+            *abserr = err2 + err3;
+            *abserr = fmax(*abserr, 5.0 * epmach * fabs(*result));
+            return;
+        }
+        e3 = epstab[k1];
+        epstab[k1] = e1;
+        delta1 = e1 - e3;
+        err1 = fabs(delta1);
+        tol1 = fmax(e1abs, fabs(e3)) * epmach;
+        /* if two elements are very close to each other, omit a part of the table */
+        if (err1 <= tol1 || err2 <= tol2 || err3 <= tol3) {
+            *n = i + i - 1;
+            break;
+        }
+        ss = 1.0 / delta1 + 1.0 / delta2 - 1.0 / delta3;
+        epsinf = fabs(ss * e1);
+        /* test to detect irregular behaviour in the table */
+        if (epsinf <= 1e-4) {
+            *n = i + i - 1;
+            break;
+        }
+        res = e1 + 1.0 / ss;
+        epstab[k1] = res;
+        k1 -= 2;
+        error = err2 + fabs(res - e2) + err3;
+        if (error <= *abserr) {
+            *abserr = error;
+            *result = res;
+        }
+    }
+    /* shift the table */
+    if (*n == limexp) *n = 2 * (limexp / 2) - 1;
+    ib = ((num / 2) * 2 == num) ? 2 : 1;
+    ie = newelm + 1;
+    for (i = 1; i <= ie; ++i) {
+        ib2 = ib + 2;
+        epstab[ib] = epstab[ib2];
+        ib = ib2;
+    }
+    if (num != *n) {
+        indx = num - *n + 1;
+        for (i = 1; i <= *n; ++i) {
+            epstab[i] = epstab[indx];
+            ++indx;
+        }
+    }
+    if (*nres < 4) {
+        res3la[*nres] = *result;
+        *abserr = oflow;
+    } else {
+        *abserr = fabs(*result - res3la[3]) + fabs(*result - res3la[2]) + fabs(*result - res3la[1]);
+        res3la[1] = res3la[2];
+        res3la[2] = res3la[3];
+        res3la[3] = *result;
+    }
+L100:
+    *abserr = fmax(*abserr, 5.0 * epmach * fabs(*result));
+}
+
+/* ---- QUADPACK dqagse specialised to the Townsend integrand ---------------------------------- */
+/* returns ier; neval_out may be NULL.  epsabs = epsrel = 1.49e-8, limit = 50 (scipy defaults). */
+int orc_quad_townsend(double a, double b, double rate, double *result_out, double *abserr_out,
+                      int32_t *neval_out) {
+    enum { LIMIT = 50 };
+    const double epsabs = 1.49e-8, epsrel = 1.49e-8;
+    const double epmach = DBL_EPSILON, uflow = DBL_MIN, oflow = DBL_MAX;
+    double alist[LIMIT + 2], blist[LIMIT + 2], rlist[LIMIT + 2], elist[LIMIT + 2], rlist2[53], res3la[4];
+    int iord[LIMIT + 2];
+    double result = 0.0, abserr = 0.0, defabs, resabs, dres, errbnd;
+    int ier = 0, last, ierro = 0;
+    memset(iord, 0, sizeof iord);
+    alist[1] = a; blist[1] = b; rlist[1] = 0.0; elist[1] = 0.0;
+    dqk21(rate, a, b, &result, &abserr, &defabs, &resabs);
+    dres = fabs(result);
+    errbnd = fmax(epsabs, epsrel * dres);
+    last = 1;
+    rlist[1] = result; elist[1] = abserr; iord[1] = 1;
+    if (abserr <= 100.0 * epmach * defabs && abserr > errbnd) ier = 2;
+    if (ier != 0 || (abserr <= errbnd && abserr != resabs) || abserr == 0.0) goto L140;
+    {
+        double errmax = abserr, area = result, errsum = abserr, small = 0.0, erlarg = 0.0, ertest = 0.0,
+               correc = 0.0, erlast, reseps, abseps;
+        int maxerr = 1, nrmax = 1, nres = 0, numrl2 = 2, ktmin = 0, extrap = 0, noext = 0;
+        int iroff1 = 0, iroff2 = 0, iroff3 = 0, ksgn = -1, k, id, jupbnd;
+        rlist2[1] = result;
+        abserr = oflow;
+        if (dres >= (1.0 - 50.0 * epmach) * defabs) ksgn = 1;
+        for (last = 2; last <= LIMIT; ++last) {
+            double a1 = alist[maxerr], b1 = 0.5 * (alist[maxerr] + blist[maxerr]), a2 = b1, b2 = blist[maxerr];
+            double area1, area2, error1, error2, defab1, defab2, area12, erro12;
+            erlast = errmax;
+            dqk21(rate, a1, b1, &area1, &error1, &resabs, &defab1);
+            dqk21(rate, a2, b2, &area2, &error2, &resabs, &defab2);
+            area12 = area1 + area2;
+            erro12 = error1 + error2;
+            errsum = errsum + erro12 - errmax;
+            area = area + area12 - rlist[maxerr];
+            if (defab1 != error1 && defab2 != error2) {
+                if (fabs(rlist[maxerr] - area12) <= 1e-5 * fabs(area12) && erro12 >= 0.99 * errmax) {
+                    if (extrap) ++iroff2; else ++iroff1;
+                }
+                if (last > 10 && erro12 > errmax) ++iroff3;
+            }
+            rlist[maxerr] = area1;
+            rlist[last] = area2;
+            errbnd = fmax(epsabs, epsrel * fabs(area));
+            if (iroff1 + iroff2 >= 10 || iroff3 >= 20) ier = 2;
+            if (iroff2 >= 5) ierro = 3;
+            if (last == LIMIT) ier = 1;
+            if (fmax(fabs(a1), fabs(b2)) <= (1.0 + 100.0 * epmach) * (fabs(a2) + 1000.0 * uflow)) ier = 4;
+            if (error2 > error1) {
+                alist[maxerr] = a2; alist[last] = a1; blist[last] = b1;
+                rlist[maxerr] = area2; rlist[last] = area1;
+                elist[maxerr] = error2; elist[last] = error1;
+            } else {
+                alist[last] = a2; blist[maxerr] = b1; blist[last] = b2;
+                elist[maxerr] = error1; elist[last] = error2;
+            }
+            dqpsrt(LIMIT, last, &maxerr, &errmax, elist, iord, &nrmax);
+            if (errsum <= errbnd) goto L115;
+            if (ier != 0) break;
+            if (last == 2) {
+                small = fabs(b - a) * 0.375;
+                erlarg = errsum;
+                ertest = errbnd;
+                rlist2[2] = area;
+                continue;
+            }
+            if (noext) continue;
+            erlarg -= erlast;
+            if (fabs(b1 - a1) > small) erlarg += erro12;
+            if (!extrap) {
+                if (fabs(blist[maxerr] - alist[maxerr]) > small) continue;
+                extrap = 1;
+                nrmax = 2;
+            }
+            if (ierro != 3 && erlarg > ertest) {
+                int found = 0;
+                id = nrmax;
+                jupbnd = last;
+                if (last > (2 + LIMIT / 2)) jupbnd = LIMIT + 3 - last;
+                for (k = id; k <= jupbnd; ++k) {
+                    maxerr = iord[nrmax];
+                    errmax = elist[maxerr];
+                    if (fabs(blist[maxerr] - alist[maxerr]) > small) { found = 1; break; }
+                    ++nrmax;
+                }
+                if (found) continue;
+            }
+            /* perform extrapolation */
+            ++numrl2;
+            rlist2[numrl2] = area;
+            dqelg(&numrl2, rlist2, &reseps, &abseps, res3la, &nres);
+            ++ktmin;
+            if (ktmin > 5 && abserr < 1e-3 * errsum) ier = 5;
+            if (abseps < abserr) {
+                ktmin = 0;
+                abserr = abseps;
+                result = reseps;
+                correc = erlarg;
+                ertest = fmax(epsabs, epsrel * fabs(reseps));
+                if (abserr <= ertest) break;
+            }
+            if (numrl2 == 1) noext = 1;
+            if (ier == 5) break;
+            maxerr = iord[1];
+            errmax = elist[maxerr];
+            nrmax = 1;
+            extrap = 0;
+            small *= 0.5;
+            erlarg = errsum;
+        }
+        if (last > LIMIT) last = LIMIT; /* loop ran to completion */
+        /* L100: set final result and error estimate */
+        if (abserr == oflow) goto L115;
+        if (ier + ierro != 0) {
+            if (ierro == 3) abserr += correc;
+            if (ier == 0) ier = 3;
+            if (result != 0.0 && area != 0.0) {
+                if (abserr / fabs(result) > errsum / fabs(area)) goto L115;
+                goto L110;
+            }
+            if (abserr > errsum) goto L115;
+            if (area == 0.0) goto L130;
+        }
+    L110:
+        if (ksgn == -1 && fmax(fabs(result), fabs(area)) <= defabs * 0.01) goto L130;
+        if (0.01 > result / area || result / area > 100.0 || errsum > fabs(area)) ier = 6;
+        goto L130;
+    L115:
+        result = 0.0;
+        for (k = 1; k <= last; ++k) result += rlist[k];
+        abserr = errsum;
+    L130:
+        if (ier > 2) --ier;
+    }
+L140:
+    *result_out = result;
+    *abserr_out = abserr;
+    if (neval_out) *neval_out = 42 * last - 21;
+    return ier;
+}
+
+/* tapir/compute.py:81-94: per interval, quad over every (finite-rate) site, then Python's
+ * sequential sum() of integrals and of errors. */
+void orc_net_integrals(const double *rates, int64_t n, const int32_t *intervals, int32_t n_i, int32_t mode,
+                       double *sum_integral, double *sum_error) {
+    for (int32_t k = 0; k < n_i; ++k) {
+        double a = (double)intervals[2 * k], b = (double)intervals[2 * k + 1];
+        double si = 0.0, se = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (!isfinite(rates[i])) continue; /* bin/tapir_compute.py:122 rates[numpy.isfinite(rates)] */
+            double r, e = 0.0;
+            if (mode == 0) orc_quad_townsend(a, b, rates[i], &r, &e, NULL);
+            else r = orc_integral_closed(a, b, rates[i]);
+            si += r; se += e;
+        }
+        sum_integral[k] = si;
+        sum_error[k] = se;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * GTR eigen-system:  Q = R o pi off-diagonal, rows sum to zero (bf:978-1001).  Symmetrise with
+ * S = D^{1/2} Q D^{-1/2}, D = diag(pi); Jacobi-rotate S = V L V^T; then exp(Qt) = U exp(Lt) U^-1 with
+ * U = D^{-1/2} V, U^-1 = V^T D^{1/2}.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { double lam[4], U[4][4], Ui[4][4], pi[4], kappa; } orc_model;
+
+static void jacobi4(double A[4][4], double V[4][4], double w[4]) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j);
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (A[p][q] == 0.0) continue;
+            double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 4; ++k) { /* A <- A J */
+                double akp = A[k][p], akq = A[k][q];
+                A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+            }
+            for (int k = 0; k < 4; ++k) { /* A <- J^T A */
+                double apk = A[p][k], aqk = A[q][k];
+                A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+            }
+            for (int k = 0; k < 4; ++k) {
+                double vkp = V[k][p], vkq = V[k][q];
+                V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+            }
+        }
+    }
+    for (int i = 0; i < 4; ++i) w[i] = A[i][i];
+}
+
+/* exch order: AC, AG, AT, CG, CT, GT (the order of the JSON "subs_matrix", bf:1024-1031) */
+static void build_model(const double pi[4], const double exch[6], orc_model *m) {
+    double R[4][4] = {{0, exch[0], exch[1], exch[2]}, {exch[0], 0, exch[3], exch[4]},
+                      {exch[1], exch[3], 0, exch[5]}, {exch[2], exch[4], exch[5], 0}};
+    double Q[4][4], S[4][4], V[4][4], sq[4];
+    m->kappa = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        double row = 0.0;
+        for (int j = 0; j < 4; ++j) if (j != i) { Q[i][j] = R[i][j] * pi[j]; row += Q[i][j]; }
+        Q[i][i] = -row;
+        m->kappa += pi[i] * row; /* = 2 sum_{i<j} pi_i pi_j r_ij : expected substitutions per unit t*s */
+        m->pi[i] = pi[i];
+        sq[i] = sqrt(pi[i]);
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) S[i][j] = sq[i] * Q[i][j] / sq[j];
+    for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) S[i][j] = S[j][i] = 0.5 * (S[i][j] + S[j][i]);
+    jacobi4(S, V, m->lam);
+    for (int i = 0; i < 4; ++i) for (int k = 0; k < 4; ++k) {
+        m->U[i][k] = V[i][k] / sq[i];
+        m->Ui[k][i] = V[i][k] * sq[i];
+    }
+}
+
+/* P(t) and its first two derivatives with respect to s at branch length t*s */
+static void transition(const orc_model *m, double t, double s, double P[4][4], double P1[4][4], double P2[4][4]) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        double p = 0, p1 = 0, p2 = 0;
+        for (int k = 0; k < 4; ++k) {
+            double d = m->lam[k] * t, e = exp(d * s), c = m->U[i][k] * m->Ui[k][j];
+            p += c * e; p1 += c * d * e; p2 += c * d * d * e;
+        }
+        P[i][j] = p; P1[i][j] = p1; P2[i][j] = p2;
+    }
+}
+
+typedef struct {
+    int32_t nnodes, ntaxa;
+    const int32_t *parent, *leaf_taxon;
+    const double *blen;
+    double *part; /* [nnodes][3][4] work space */
+} orc_tree;
+
+/* log L(s) and derivatives wrt u = log s for one column (pruning, bf:1053 evaluates this through
+ * LikelihoodFunction siteLikelihood = (siteFilter, siteTree)). */
+static void column_loglik(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols,
+                          int64_t col, double u, double *f, double *g, double *h) {
+    double s = exp(u);
+    double(*X)[3][4] = (double(*)[3][4])tr->part;
+    int scale = 0;
+    for (int n = 0; n < tr->nnodes; ++n) {
+        if (tr->leaf_taxon[n] >= 0) {
+            unsigned mask = states[(int64_t)tr->leaf_taxon[n] * ncols + col] & 15u;
+            if (mask == 0) mask = 15u;
+            for (int i = 0; i < 4; ++i) { X[n][0][i] = (mask >> i) & 1u; X[n][1][i] = 0; X[n][2][i] = 0; }
+        } else {
+            for (int i = 0; i < 4; ++i) { X[n][0][i] = 1; X[n][1][i] = 0; X[n][2][i] = 0; }
+        }
+    }
+    for (int n = 0; n < tr->nnodes; ++n) {
+        int p = tr->parent[n];
+        if (p < 0) continue;
+        double P[4][4], P1[4][4], P2[4][4], m0[4], m1[4], m2[4];
+        /* rescale an internal node whose partials got small (keeps 256+ taxa inside fp64 range) */
+        if (tr->leaf_taxon[n] < 0) {
+            double mx = fmax(fmax(X[n][0][0], X[n][0][1]), fmax(X[n][0][2], X[n][0][3]));
+            if (mx > 0 && mx < 1e-100) {
+                int e; frexp(mx, &e);
+                for (int d = 0; d < 3; ++d) for (int i = 0; i < 4; ++i) X[n][d][i] = ldexp(X[n][d][i], -e);
+                scale += e;
+            }
+        }
+        transition(m, tr->blen[n], s, P, P1, P2);
+        for (int i = 0; i < 4; ++i) {
+            m0[i] = m1[i] = m2[i] = 0;
+            for (int j = 0; j < 4; ++j) {
+                m0[i] += P[i][j] * X[n][0][j];
+                m1[i] += P1[i][j] * X[n][0][j] + P[i][j] * X[n][1][j];
+                m2[i] += P2[i][j] * X[n][0][j] + 2 * P1[i][j] * X[n][1][j] + P[i][j] * X[n][2][j];
+            }
+        }
+        for (int i = 0; i < 4; ++i) { /* product rule into the parent */
+            double a0 = X[p][0][i], a1 = X[p][1][i], a2 = X[p][2][i];
+            X[p][0][i] = a0 * m0[i];
+            X[p][1][i] = a1 * m0[i] + a0 * m1[i];
+            X[p][2][i] = a2 * m0[i] + 2 * a1 * m1[i] + a0 * m2[i];
+        }
+    }
+    int root = tr->nnodes - 1;
+    double L = 0, L1 = 0, L2 = 0;
+    for (int i = 0; i < 4; ++i) { L += m->pi[i] * X[root][0][i]; L1 += m->pi[i] * X[root][1][i]; L2 += m->pi[i] * X[root][2][i]; }
+    double gs = L1 / L, hs = L2 / L - gs * gs; /* d/ds, d2/ds2 of log L */
+    *f = log(L) + scale * 0.6931471805599453;
+    *g = s * gs;
+    *h = s * s * hs + s * gs;
+}
+
+/* Safeguarded Newton on u = log s from u = 0, to the local maximum uphill of the start. */
+static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
+                            double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
+    double u = 0, lo = ORC_U_MIN, hi = ORC_U_MAX, f = 0, g, h;
+    int lo_open = 1, hi_open = 1; /* bracket ends not evaluated yet */
+    *flag_out = 4;
+    for (int it = 0; it < ORC_MAXIT; ++it) {
+        column_loglik(m, tr, states, ncols, col, u, &f, &g, &h);
+        ++*neval;
+        int uphill = !(g <= 0); /* NaN (L underflowed to 0 at tiny s) counts as uphill */
+        if (u >= ORC_U_MAX && uphill) { *flag_out = 2; break; }
+        if (u <= ORC_U_MIN && !uphill) { *flag_out = 3; break; }
+        if (uphill) { lo = u; lo_open = 0; } else { hi = u; hi_open = 0; }
+        double step = (h < 0) ? -g / h : (uphill ? ORC_STEP_MAX : -ORC_STEP_MAX);
+        if (!(step <= ORC_STEP_MAX)) step = ORC_STEP_MAX;
+        if (step < -ORC_STEP_MAX) step = -ORC_STEP_MAX;
+        double un = u + step;
+        if (un >= hi) un = hi_open ? ORC_U_MAX : 0.5 * (lo + hi);
+        else if (un <= lo) un = lo_open ? ORC_U_MIN : 0.5 * (lo + hi);
+        step = un - u;
+        if (fabs(step) < ORC_STEP_TOL) { /* converged: take the last step with its quadratic model */
+            f += g * step + 0.5 * h * step * step;
+            u = un;
+            *flag_out = 0;
+            break;
+        }
+        u = un;
+    }
+    *s_out = exp(u);
+    *f_out = f;
+}
+
+/* One locus.  Outputs per column: rate = kappa*s (bf:1061), subst = rate*chronoLength (bf:1056-1060),
+ * lnl, flag, nres = number of plain A/C/G/T cells (tapir/compute.py:104). Returns total evaluations. */
+int64_t orc_site_rates(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                       const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
+                       double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
+    orc_model m;
+    orc_tree tr = {nnodes, ntaxa, parent, leaf_taxon, blen, NULL};
+    int64_t total_eval = 0;
+    double chrono = 0.0;
+    build_model(pi, exch, &m);
+    for (int n = 0; n < nnodes; ++n) if (parent[n] >= 0) chrono += blen[n]; /* bf:1006-1013 */
+    tr.part = (double *)malloc(sizeof(double) * 12 * (size_t)nnodes);
+    for (int64_t c = 0; c < ncols; ++c) {
+        unsigned uni = 0; int informative = 0, resolved = 0;
+        for (int n = 0; n < nnodes; ++n) {
+            if (leaf_taxon[n] < 0) continue;
+            unsigned mask = states[(int64_t)leaf_taxon[n] * ncols + c] & 15u;
+            if (mask == 0) mask = 15u;
+            if (mask != 15u) { uni |= mask; ++resolved; }
+            if (mask == 1u || mask == 2u || mask == 4u || mask == 8u) ++informative;
+        }
+        nres_out[c] = informative;
+        double s, f; uint8_t fl; int32_t ne = 0;
+        if (resolved <= 1) {
+            /* flat: L(s) = pi_x (or 1): independent of s; siteRate keeps its start value 1 (bf:1050) */
+            double g, h; column_loglik(&m, &tr, states, ncols, c, 0.0, &f, &g, &h); ne = 1;
+            s = 1.0; fl = 1;
+        } else if ((uni & (uni - 1)) == 0) {
+            /* every resolved taxon carries the same base x: L(s) <= pi_x = L(0), optimum at s = 0 */
+            int x = (uni == 1) ? 0 : (uni == 2) ? 1 : (uni == 4) ? 2 : 3;
+            s = 0.0; f = log(m.pi[x]); fl = 3;
+        } else {
+            maximise_column(&m, &tr, states, ncols, c, &s, &f, &fl, &ne);
+        }
+        total_eval += ne;
+        rate[c] = s * m.kappa;
+        subst[c] = rate[c] * chrono;
+        lnl[c] = f;
+        flag[c] = fl;
+    }
+    free(tr.part);
+    return total_eval;
+}
+
+/* log-likelihood curve of one column at given u values (used by tests to check derivatives) */
+void orc_column_curve(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                      const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch, int64_t col,
+                      const double *u, int32_t nu, double *f, double *g, double *h) {
+    orc_model m;
+    orc_tree tr = {nnodes, ntaxa, parent, leaf_taxon, blen, NULL};
+    build_model(pi, exch, &m);
+    tr.part = (double *)malloc(sizeof(double) * 12 * (size_t)nnodes);
+    for (int i = 0; i < nu; ++i) column_loglik(&m, &tr, states, ncols, col, u[i], &f[i], &g[i], &h[i]);
+    free(tr.part);
+}
+
+/* eigen-system export for tests: lam[4], U[16], Ui[16], kappa */
+void orc_gtr_eigen(const double *pi, const double *exch, double *lam, double *U, double *Ui, double *kappa) {
+    orc_model m;
+    build_model(pi, exch, &m);
+    memcpy(lam, m.lam, sizeof m.lam);
+    memcpy(U, m.U, sizeof m.U);
+    memcpy(Ui, m.Ui, sizeof m.Ui);
+    *kappa = m.kappa;
+}
+
+/* tapir/compute.py:96-106: per column count of cells whose character is one of A,T,G,C */
+void orc_informative_counts(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t *counts) {
+    for (int64_t c = 0; c < ncols; ++c) {
+        int k = 0;
+        for (int t = 0; t < ntaxa; ++t) {
+            unsigned mask = states[(int64_t)t * ncols + c] & 15u;
+            k += (mask == 1u || mask == 2u || mask == 4u || mask == 8u);
+        }
+        counts[c] = k;
+    }
+}
