@@ -1,0 +1,182 @@
+/*
+ * tphip.h -- C ABI of libtphip.so: the MI355X (gfx950) site-rate + phylogenetic-informativeness engine.
+ *
+ * This is the drop-in boundary for ONE hot path of faircloth-lab/tapir: what `worker()` in
+ * bin/tapir_compute.py:84-123 does per locus -- the shell-out to HyPhy (per-site substitution-rate ML,
+ * tapir/data/models_and_rates.bf:978-1070) followed by Townsend's PI(t), its per-locus sums and its
+ * scipy.integrate.quad interval integrals (tapir/compute.py:46-52, 76-94, 96-110) -- computed for ALL
+ * loci in one column-parallel batch on the GPU.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  No exceptions cross the boundary.
+ *   - every function returns 0 on success, non-zero on error; tphip_last_error() gives the message
+ *     (thread-local, owned by the library).
+ *   - there is NO CPU backend: a call fails with TPHIP_ERR_NO_DEVICE when no gfx950 device is usable.
+ *   - the caller owns every data buffer.  `*_dev` entry points take DEVICE pointers (the hot path: inputs
+ *     already resident in HBM, nothing leaves the device); the plain entry points take HOST pointers and
+ *     do the H2D/D2H copies themselves.  The library keeps no pointer past the return of a host-pointer
+ *     call; a plan keeps only its own small device tables (tree program, per-locus models, schedule).
+ *   - state codes: one byte per alignment cell, bit mask A=1 C=2 G=4 T=8; gap/?/N = 15; IUPAC codes are
+ *     unions (HyPhy resolves ambiguities as sets in the likelihood and fractionally in
+ *     HarvestFrequencies, bf:968).  Layout is TAXON-MAJOR over the flattened batch:
+ *     states[taxon * ncols_total + column]; loci are concatenated along the column axis and
+ *     locus_offsets[L+1] gives their column ranges.  A wave reads 64 consecutive bytes of one taxon row.
+ *   - tree: nodes in post-order (children before parents, root last); parent[root] = -1; leaf_taxon[n] =
+ *     alignment row of leaf n, -1 for internal nodes; branch_len[n] = length of the branch above n,
+ *     ALREADY divided by the correction factor (tapir/compute.py:59-74).  Multifurcations allowed.
+ *   - PI table row for a locus: [ net PI at t=0..T-1 | PI at each of n_t times | sum(integral) per
+ *     interval | sum(error) per interval ],  W = T + n_t + 2*n_i doubles (what tapir/db.py:44-61 stores).
+ */
+#ifndef TPHIP_H
+#define TPHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPHIP_VERSION 100 /* 0.1.0 */
+
+enum {
+    TPHIP_OK = 0,
+    TPHIP_ERR_INVALID = 1,   /* bad argument (message says which) */
+    TPHIP_ERR_NO_DEVICE = 2, /* no usable GPU: the library has no CPU path */
+    TPHIP_ERR_HIP = 3,       /* a HIP runtime call failed */
+    TPHIP_ERR_WORKSPACE = 4  /* caller's workspace is too small */
+};
+
+/* per-column flags written by the site-rate kernel */
+enum {
+    TPHIP_FLAG_OK = 0,        /* interior optimum                                                   */
+    TPHIP_FLAG_FLAT = 1,      /* <= 1 resolved taxon: L independent of the rate; s stays 1 (bf:1050)  */
+    TPHIP_FLAG_SATURATED = 2, /* likelihood still increasing at s = 1e4                              */
+    TPHIP_FLAG_ZERO = 3,      /* all resolved taxa share one base: optimum exactly at s = 0          */
+    TPHIP_FLAG_MAXIT = 4      /* iteration limit                                                     */
+};
+
+/* integral modes for the interval sums (tapir/compute.py:50-52, 81-94) */
+enum {
+    TPHIP_INTEG_QUADPACK = 0, /* emulates scipy.integrate.quad: QUADPACK dqagse, GK21, eps 1.49e-8, limit 50;
+                                 also yields sum(error) for the sqlite `interval.error` column          */
+    TPHIP_INTEG_CLOSED = 1    /* analytic antiderivative -(4rt+1)exp(-4rt); error column = 0            */
+};
+
+int tphip_version(void);
+const char *tphip_last_error(void);
+/* number of usable HIP devices (0 if none; never fails) */
+int tphip_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Plan: everything that is small and shared by a batch -- the tree's traversal program, the per-locus
+ * GTR models (eigen-systems are computed on the device), the column ranges and the PI schedule.
+ * Replaces: the three stdin lines + in-script constants HyPhy is configured with (bf:4-9, 966-1013) and
+ * the per-locus `params` list of bin/tapir_compute.py:148-152.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tphip_plan tphip_plan;
+
+typedef struct tphip_plan_desc {
+    int32_t device;            /* HIP device ordinal (>= 0)                                            */
+    /* tree (host pointers) */
+    int32_t ntaxa;             /* rows of the alignment                                                */
+    int32_t nnodes;            /* nodes of the tree, post-order                                        */
+    const int32_t *parent;     /* [nnodes]                                                             */
+    const double *branch_len;  /* [nnodes], already / correction                                       */
+    const int32_t *leaf_taxon; /* [nnodes]                                                             */
+    /* loci (host pointers) */
+    int64_t nloci;
+    const int64_t *locus_offsets; /* [nloci+1] column ranges in the flattened batch                    */
+    const double *pi;          /* [nloci*4] A,C,G,T base frequencies (bf:968 HarvestFrequencies)       */
+    const double *exch;        /* [nloci*6] AC,AG,AT,CG,CT,GT exchangeabilities (bf:970-976; AG == 1)  */
+    /* PI schedule */
+    int32_t T;                 /* net PI is evaluated at t = 0..T-1, T = int(tree depth) (compute.py:54-57) */
+    const int32_t *times;      /* [n_t] --times, each < T (compute.py:76-79)                           */
+    int32_t n_t;
+    const int32_t *intervals;  /* [n_i*2] --intervals as (start, stop), start < stop (compute.py:90-91) */
+    int32_t n_i;
+    int32_t integ_mode;        /* TPHIP_INTEG_*                                                        */
+    /* rate post-processing between the two stages (bin/tapir_compute.py:100-102) */
+    double correction;         /* rates are divided by this (parse_site_rates, compute.py:38-39)       */
+    int32_t threshold;         /* columns with fewer A/C/G/T cells become NaN (compute.py:96-110)      */
+    int32_t round_decimals;    /* 4 = round rates as HyPhy's Format(x,0,4) does before PI (bf:1093-1095);
+                                  < 0 = keep full precision                                            */
+} tphip_plan_desc;
+
+int tphip_plan_create(const tphip_plan_desc *desc, tphip_plan **out);
+int tphip_plan_destroy(tphip_plan *plan);
+/* width W of a PI table row, and total columns */
+int32_t tphip_plan_table_width(const tphip_plan *plan);
+int64_t tphip_plan_ncols(const tphip_plan *plan);
+/* bytes of device scratch the *_dev entry points need (compacted column list, per-chunk PI partials) */
+size_t tphip_plan_workspace_bytes(const tphip_plan *plan);
+/* chronogram length = sum of branch lengths (bf:1006-1013) and LDS stack depth of the program */
+double tphip_plan_chrono_length(const tphip_plan *plan);
+int32_t tphip_plan_stack_depth(const tphip_plan *plan);
+/* copy the per-locus eigen-systems back (tests): lam[L*4], U[L*16], Uinv[L*16], kappa[L] */
+int tphip_plan_get_models(const tphip_plan *plan, double *lam, double *U, double *Uinv, double *kappa);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-pointer entry points (the hot path).  `stream` is a hipStream_t (NULL = default stream).
+ * Kernels are enqueued and the call returns without synchronising.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Stage 1 -- replaces Popen([hyphy, template]) for every locus at once (bin/tapir_compute.py:92-99).
+ * Per column: rate = kappa*s_hat, subst = rate*chronoLength, lnl, flag, nres = #A/C/G/T cells. */
+int tphip_site_rates_dev(tphip_plan *plan, const uint8_t *d_states, double *d_rate, double *d_subst,
+                         double *d_lnl, uint8_t *d_flag, int32_t *d_nres, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* Stage 2 -- replaces get_townsend_pi + nansum + get_net_pi_for_periods + get_net_integral_for_epochs
+ * (bin/tapir_compute.py:114-122).  d_rates are the raw stage-1 rates; rounding, /correction and the
+ * informative-site cull (d_nres may be NULL = no cull, the --site-rates path, bin/tapir_compute.py:103-104)
+ * are applied on the fly.  d_tables is [nloci][W]. */
+int tphip_pi_tables_dev(tphip_plan *plan, const double *d_rates, const int32_t *d_nres, double *d_tables,
+                        void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Both stages back to back on one stream: the whole worker() body for the whole batch. */
+int tphip_run_dev(tphip_plan *plan, const uint8_t *d_states, double *d_rate, double *d_subst, double *d_lnl,
+                  uint8_t *d_flag, int32_t *d_nres, double *d_tables, void *d_workspace,
+                  size_t workspace_bytes, void *stream);
+
+/* tapir/compute.py:46-48 get_townsend_pi(time, rates) as a dense (n_times, n) matrix, row-major:
+ * out[k*n + i] = 16 r_i^2 t_k exp(-4 r_i t_k).  NaN rates propagate (numpy semantics). */
+int tphip_townsend_pi_dense_dev(int32_t device, const double *d_rates, int64_t n, const double *d_times,
+                                int32_t n_times, double *d_out, void *stream);
+
+/* tapir/compute.py:50-52 vectorised over sites: (integral, abserr) of scipy.integrate.quad(
+ * get_townsend_pi, a, b, args=(rate)) for every rate (QUADPACK dqagse emulation, or the closed form with
+ * abserr = 0 when integ_mode == TPHIP_INTEG_CLOSED).  Non-finite rates give NaN. */
+int tphip_quad_townsend_dev(int32_t device, const double *d_rates, int64_t n, double a, double b,
+                            int32_t integ_mode, double *d_integral, double *d_abserr, void *stream);
+
+/* HarvestFrequencies(Freqs, filter, 1, 1, 1) (bf:968): per-locus counts of each of the 16 state masks;
+ * d_hist is [nloci][16] int64 (pi follows on the host: each mask adds 1/popcount to its bases). */
+int tphip_state_histogram_dev(tphip_plan *plan, const uint8_t *d_states, int64_t *d_hist, void *stream);
+
+/* Profiling hooks for bench.py: when enabled the library brackets its dominant kernel (site rates) with
+ * HIP events on the caller's stream and accumulates the elapsed time. */
+int tphip_profile_enable(tphip_plan *plan, int32_t on);
+/* sums since the last reset; *launches = number of bracketed launches; the call synchronises the events */
+int tphip_profile_read(tphip_plan *plan, double *site_rate_ms, double *pi_ms, int64_t *launches, int32_t reset);
+/* total likelihood evaluations (Newton iterations summed over columns) of the last site-rate launch */
+int tphip_last_eval_count(tphip_plan *plan, int64_t *evals);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-pointer entry points: same stages, library does the copies (PCIe time included by construction).
+ * ---------------------------------------------------------------------------------------------- */
+int tphip_site_rates(tphip_plan *plan, const uint8_t *states, double *rate, double *subst, double *lnl,
+                     uint8_t *flag, int32_t *nres);
+int tphip_pi_tables(tphip_plan *plan, const double *rates, const int32_t *nres, double *tables);
+int tphip_run_fused(tphip_plan *plan, const uint8_t *states, double *rate, double *subst, double *lnl,
+                    uint8_t *flag, int32_t *nres, double *tables);
+int tphip_townsend_pi_dense(int32_t device, const double *rates, int64_t n, const double *times, int32_t n_times,
+                            double *out);
+int tphip_quad_townsend(int32_t device, const double *rates, int64_t n, double a, double b, int32_t integ_mode,
+                        double *integral, double *abserr);
+int tphip_state_histogram(tphip_plan *plan, const uint8_t *states, int64_t *hist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPHIP_H */

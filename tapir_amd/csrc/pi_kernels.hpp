@@ -1,0 +1,288 @@
+// pi_kernels.hpp -- column classification / compaction and the PI-table kernels.
+//
+// classify_kernel + compact_kernel   (HBM-bound byte work: ntaxa bytes read per column)
+//     replace HyPhy's unique-pattern bookkeeping (bf:1033-1044) and tapir's informative-site count
+//     (tapir/compute.py:96-106): per column the number of plain A/C/G/T cells, and whether the likelihood
+//     has a closed-form maximiser (all resolved taxa identical -> s = 0; <= 1 resolved taxon -> flat).
+// pi_partial_kernel + pi_reduce_kernel
+//     replace bin/tapir_compute.py:114-122: pi = get_townsend_pi(time_vector, rates) is never materialised;
+//     the (T x S) matrix is reduced over S on the fly into per-locus rows
+//     [net PI(t=0..T-1) | PI at --times | sum(integral) per interval | sum(error) per interval].
+//     Summation order is fixed (1024-column blocks, lane-strided, then block order) so a locus gives the
+//     same bits no matter how many GPUs the batch is sharded over.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "gtr_model.hpp"
+#include "quadpack_device.hpp"
+#include "tphip.h"
+
+namespace tphip {
+
+constexpr int kPiBlock = 256;
+constexpr int kPiColsPerThread = 4;
+constexpr int kPiChunk = kPiBlock * kPiColsPerThread;  // 1024 columns per workgroup
+constexpr int kTimeTile = 16;
+
+struct ClassifyParams {
+    const uint8_t* states;
+    int64_t ncols_total;
+    int32_t ntaxa;
+    const LocusModel* models;
+    const int64_t* locus_offsets;
+    const int32_t* chunk_locus;   // PI chunks (1024 columns, one locus each)
+    const int32_t* chunk_index;
+    double* rate;
+    double* subst;
+    double* lnl;
+    uint8_t* flag;
+    int32_t* nres;
+    double chrono_length;
+};
+
+// One thread per column; a wave reads 64 consecutive bytes of each taxon row.
+__global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
+    const int locus = P.chunk_locus[blockIdx.x];
+    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+    const LocusModel* __restrict__ M = P.models + locus;
+    const int64_t base = lo + (int64_t)P.chunk_index[blockIdx.x] * kPiChunk;
+#pragma unroll
+    for (int j = 0; j < kPiColsPerThread; ++j) {
+        const int64_t col = base + j * kPiBlock + threadIdx.x;
+        if (col >= hi) continue;
+        unsigned uni = 0;
+        int resolved = 0, informative = 0;
+        const uint8_t* p = P.states + col;
+        for (int t = 0; t < P.ntaxa; ++t) {
+            unsigned m = p[(int64_t)t * P.ncols_total] & 15u;
+            m = m ? m : 15u;
+            const bool res = (m != 15u);
+            uni |= res ? m : 0u;
+            resolved += res;
+            informative += (__popc(m) == 1);
+        }
+        P.nres[col] = informative;
+        uint8_t flg = TPHIP_FLAG_OK;  // provisional: site_rate_kernel will overwrite
+        if (resolved <= 1) flg = TPHIP_FLAG_FLAT;
+        else if (__popc(uni) == 1) flg = TPHIP_FLAG_ZERO;
+        P.flag[col] = flg;
+        if (flg != TPHIP_FLAG_OK) {
+            // L = sum over the states allowed by the one informative mask of pi_x (1 if nothing is resolved)
+            double L = 0;
+            if (uni == 0) L = 1.0;
+            else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) L += ((uni >> x) & 1u) ? M->pi[x] : 0.0;
+            }
+            const double s = (flg == TPHIP_FLAG_FLAT) ? 1.0 : 0.0;  // flat: siteRate keeps its start value (bf:1050)
+            const double r = s * M->kappa;
+            P.rate[col] = r;
+            P.subst[col] = r * P.chrono_length;
+            P.lnl[col] = log(L);
+        }
+    }
+}
+
+// One workgroup per locus: stable compaction of the columns that still need the optimiser.
+__global__ __launch_bounds__(256) void compact_kernel(const uint8_t* __restrict__ flag, const int64_t* __restrict__ locus_offsets,
+                                                      int32_t* __restrict__ work_cols, int32_t* __restrict__ work_count) {
+    __shared__ int wave_tot[4];
+    __shared__ int running;
+    const int locus = blockIdx.x;
+    const int64_t lo = locus_offsets[locus], hi = locus_offsets[locus + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int64_t base = lo; base < hi; base += 256) {
+        const int64_t col = base + threadIdx.x;
+        const bool want = (col < hi) && (flag[col] == TPHIP_FLAG_OK);
+        const unsigned long long bal = __ballot(want);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        if (want) work_cols[lo + off + before] = (int32_t)col;
+        __syncthreads();
+        if (threadIdx.x == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) work_count[locus] = running;
+}
+
+struct PiParams {
+    const double* rates;       // raw stage-1 rates (kappa * s) or user-supplied rates
+    const int32_t* nres;       // may be null (no cull)
+    const int64_t* locus_offsets;
+    const int32_t* chunk_locus;
+    const int32_t* chunk_index;
+    int32_t T;
+    const int32_t* intervals;  // [n_i][2]
+    int32_t n_i;
+    int32_t integ_mode;
+    double correction;
+    int32_t threshold;
+    double round_scale;        // 10^decimals, or 0 for no rounding
+    double* partial;           // [nchunks][T + 2 n_i]
+};
+
+// rate as tapir sees it after the JSON round trip, the /correction and the cull
+// (bf:1093-1095 Format(x,0,4); tapir/compute.py:38-39; tapir/compute.py:96-110)
+__device__ __forceinline__ double finalize_rate(const PiParams& P, int64_t col) {
+    double r = P.rates[col];
+    if (P.round_scale > 0.0) r = rint(r * P.round_scale) / P.round_scale;
+    r = r / P.correction;
+    if (P.nres && P.nres[col] < P.threshold) r = __longlong_as_double(0x7ff8000000000000ll);
+    return r;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(kPiBlock) void pi_partial_kernel(PiParams P) {
+    __shared__ double red[kTimeTile][4];
+    const int chunk = blockIdx.x;
+    const int locus = P.chunk_locus[chunk];
+    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+    const int64_t base = lo + (int64_t)P.chunk_index[chunk] * kPiChunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double r[kPiColsPerThread];
+    bool ok[kPiColsPerThread];
+#pragma unroll
+    for (int j = 0; j < kPiColsPerThread; ++j) {
+        const int64_t col = base + j * kPiBlock + threadIdx.x;
+        r[j] = (col < hi) ? finalize_rate(P, col) : __longlong_as_double(0x7ff8000000000000ll);
+        ok[j] = isfinite(r[j]);  // nansum skips NaN (bin/tapir_compute.py:119); quad only sees finite rates (:122)
+    }
+    const int Wp = P.T + 2 * P.n_i;
+    double* out = P.partial + (size_t)chunk * Wp;
+    // ---- net PI(t), t = 0..T-1, in tiles of kTimeTile time points
+    for (int t0 = 0; t0 < P.T; t0 += kTimeTile) {
+        double acc[kTimeTile];
+#pragma unroll
+        for (int i = 0; i < kTimeTile; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < kPiColsPerThread; ++j) {
+            if (!ok[j]) continue;
+            const double c = 16.0 * (r[j] * r[j]);
+            const double q = exp(-(4.0 * r[j]));
+            double p = exp(-(4.0 * r[j] * (double)t0));
+#pragma unroll
+            for (int i = 0; i < kTimeTile; ++i) {
+                acc[i] = fma(c * (double)(t0 + i), p, acc[i]);
+                p *= q;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kTimeTile; ++i) {
+            const double s = wave_sum(acc[i]);
+            if (lane == 0) red[i][wave] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < kTimeTile && t0 + threadIdx.x < P.T)
+            out[t0 + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+        __syncthreads();
+    }
+    // ---- interval integrals
+    for (int k = 0; k < P.n_i; ++k) {
+        const double a = (double)P.intervals[2 * k], b = (double)P.intervals[2 * k + 1];
+        double si = 0.0, se = 0.0;
+#pragma unroll 1
+        for (int j = 0; j < kPiColsPerThread; ++j) {
+            if (!ok[j]) continue;
+            double res, err = 0.0;
+            if (P.integ_mode == TPHIP_INTEG_QUADPACK) quad_townsend(a, b, r[j], res, err);
+            else res = integral_closed(a, b, r[j]);
+            si += res;
+            se += err;
+        }
+        si = wave_sum(si);
+        se = wave_sum(se);
+        if (lane == 0) { red[0][wave] = si; red[1][wave] = se; }
+        __syncthreads();
+        if (threadIdx.x < 2)
+            out[P.T + threadIdx.x * P.n_i + k] =
+                ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+        __syncthreads();
+    }
+}
+
+// tables[l] = [net(T) | disc(n_t) | integral(n_i) | error(n_i)], summing the locus' chunks in order.
+__global__ void pi_reduce_kernel(const double* __restrict__ partial, const int64_t* __restrict__ locus_chunk_offsets,
+                                 int32_t T, const int32_t* __restrict__ times, int32_t n_t, int32_t n_i,
+                                 double* __restrict__ tables) {
+    const int locus = blockIdx.x;
+    const int64_t c0 = locus_chunk_offsets[locus], c1 = locus_chunk_offsets[locus + 1];
+    const int Wp = T + 2 * n_i, W = T + n_t + 2 * n_i;
+    double* row = tables + (size_t)locus * W;
+    for (int w = threadIdx.x; w < Wp + n_t; w += blockDim.x) {
+        // w < Wp: a partial column; else a --times entry, which is net[times[k]] (tapir/compute.py:76-79)
+        const int src = (w < Wp) ? w : times[w - Wp];
+        double s = 0.0;
+        for (int64_t c = c0; c < c1; ++c) s += partial[(size_t)c * Wp + src];
+        const int dst = (w < T) ? w : (w < Wp ? w + n_t : T + (w - Wp));
+        row[dst] = s;
+    }
+}
+
+// tapir/compute.py:46-48 as a dense (n_times, n) matrix: out[k*n + i] = 16 r_i^2 t_k exp(-4 r_i t_k).
+// Pure streaming: 8 B read per site, 8*n_times B written; consecutive lanes write consecutive doubles.
+__global__ void townsend_dense_kernel(const double* __restrict__ rates, int64_t n, const double* __restrict__ times,
+                                      int32_t n_times, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double r = rates[i];
+    for (int k = 0; k < n_times; ++k) out[(size_t)k * n + i] = townsend_pi(times[k], r);
+}
+
+// tapir/compute.py:50-52 vectorised over sites (what numpy.vectorize(get_integral_over_times) returns)
+__global__ void quad_sites_kernel(const double* __restrict__ rates, int64_t n, double a, double b, int32_t integ_mode,
+                                  double* __restrict__ integral, double* __restrict__ abserr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double r = rates[i];
+    double res = __longlong_as_double(0x7ff8000000000000ll), err = res;
+    if (isfinite(r)) {
+        err = 0.0;
+        if (integ_mode == TPHIP_INTEG_QUADPACK) quad_townsend(a, b, r, res, err);
+        else res = integral_closed(a, b, r);
+    }
+    integral[i] = res;
+    abserr[i] = err;
+}
+
+// per-locus histogram of the 16 state masks (HarvestFrequencies, bf:968)
+__global__ __launch_bounds__(256) void state_histogram_kernel(const uint8_t* __restrict__ states, int64_t ncols_total,
+                                                              int32_t ntaxa, const int64_t* __restrict__ locus_offsets,
+                                                              unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int h[16];
+    const int locus = blockIdx.x;
+    const int64_t lo = locus_offsets[locus], hi = locus_offsets[locus + 1];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int mine[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) mine[m] = 0;
+    for (int t = 0; t < ntaxa; ++t) {
+        const uint8_t* row = states + (int64_t)t * ncols_total;
+        for (int64_t c = lo + threadIdx.x; c < hi; c += blockDim.x) {
+            unsigned m = row[c] & 15u;
+            m = m ? m : 15u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mine[k] += (m == (unsigned)k);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        unsigned v = mine[m];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&h[m], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) hist[(size_t)locus * 16 + threadIdx.x] = h[threadIdx.x];
+}
+
+}  // namespace tphip

@@ -1,0 +1,350 @@
+// quadpack_device.hpp -- device-side emulation of scipy.integrate.quad for Townsend's PI(t).
+//
+// Reference behaviour replaced: tapir/compute.py:50-52, 81-94 -- one `integrate.quad(get_townsend_pi, a, b,
+// args=(rate))` per (site, interval); scipy's quad with default arguments on a finite interval is QUADPACK
+// `dqagse` (21-point Gauss-Kronrod pairs, epsabs = epsrel = 1.49e-8, limit = 50, Wynn epsilon
+// extrapolation).  The sqlite `interval.error` column stores the SUM of its abserr outputs
+// (tapir/compute.py:92-93, tapir/db.py:57-60), so the whole routine -- not just the quadrature rule -- is
+// implemented: a fast path (the first GK21 panel is accepted for almost every site) kept in registers, and
+// the full adaptive bisection + extrapolation as a rarely-taken out-of-line slow path using scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+
+namespace tphip {
+
+// Townsend 2007 eq. 10 as coded in tapir/compute.py:46-48, same operation order.
+__device__ __forceinline__ double townsend_pi(double t, double r) { return 16.0 * (r * r) * t * exp(-(4.0 * r * t)); }
+
+struct GK21 {
+    double result, abserr, resabs, resasc;
+};
+
+__device__ __constant__ const double kXgk[11] = {
+    0.995657163025808080735527280689003, 0.973906528517171720077964012084452, 0.930157491355708226001207180059508,
+    0.865063366688984510732096688423493, 0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+    0.562757134668604683339000099272694, 0.433395394129247190799265943165784, 0.294392862701460198131126603103866,
+    0.148874338981631210884826001129720, 0.0};
+__device__ __constant__ const double kWgk[11] = {
+    0.011694638867371874278064396062192, 0.032558162307964727478818972459390, 0.054755896574351996031381300244580,
+    0.075039674810919952767043140916190, 0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+    0.123491976262065851077958109585166, 0.134709217311473325928054001771707, 0.142775938577060080797094273138717,
+    0.147739104901338491374841515972068, 0.149445554002916905664936468389821};
+__device__ __constant__ const double kWg[5] = {
+    0.066671344308688137593568809893332, 0.149451349150580593145776339657697, 0.219086362515982043995534934228163,
+    0.269266719309996355091226921569469, 0.295524224714752870173815619188769};
+
+// QUADPACK dqk21 on [a,b] for f(t) = townsend_pi(t, rate).  The Kronrod sum runs in QUADPACK's order
+// (centre, the five Gauss abscissae, then the five Kronrod-only ones) so the result rounds as scipy's does.
+__device__ __forceinline__ GK21 dqk21(double rate, double a, double b) {
+    const double epmach = DBL_EPSILON, uflow = DBL_MIN;
+    double fv1[10], fv2[10];
+    const double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    double resg = 0.0;
+    const double fc = townsend_pi(centr, rate);
+    double resk = kWgk[10] * fc;
+    double resabs = fabs(resk);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int jtw = 2 * j + 1;
+        const double absc = hlgth * kXgk[jtw];
+        const double f1 = townsend_pi(centr - absc, rate), f2 = townsend_pi(centr + absc, rate);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        const double fsum = f1 + f2;
+        resg += kWg[j] * fsum;
+        resk += kWgk[jtw] * fsum;
+        resabs += kWgk[jtw] * (fabs(f1) + fabs(f2));
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int jtwm1 = 2 * j;
+        const double absc = hlgth * kXgk[jtwm1];
+        const double f1 = townsend_pi(centr - absc, rate), f2 = townsend_pi(centr + absc, rate);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        const double fsum = f1 + f2;
+        resk += kWgk[jtwm1] * fsum;
+        resabs += kWgk[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    const double reskh = resk * 0.5;
+    double resasc = kWgk[10] * fabs(fc - reskh);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) resasc += kWgk[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    GK21 o;
+    o.result = resk * hlgth;
+    o.resabs = resabs * dhlgth;
+    o.resasc = resasc * dhlgth;
+    double abserr = fabs((resk - resg) * hlgth);
+    if (o.resasc != 0.0 && abserr != 0.0) {
+        const double q = 200.0 * abserr / o.resasc;
+        const double q15 = q * sqrt(q);  // q^1.5
+        abserr = o.resasc * fmin(1.0, q15);
+    }
+    if (o.resabs > uflow / (50.0 * epmach)) abserr = fmax((epmach * 50.0) * o.resabs, abserr);
+    o.abserr = abserr;
+    return o;
+}
+
+// QUADPACK dqpsrt (1-based lists as published)
+__device__ inline void dqpsrt(int limit, int last, int* maxerr, double* ermax, const double* elist, int* iord, int* nrmax) {
+    if (last <= 2) {
+        iord[1] = 1; iord[2] = 2;
+    } else {
+        const double errmax = elist[*maxerr];
+        if (*nrmax != 1) {
+            const int ido = *nrmax - 1;
+            for (int i = 1; i <= ido; ++i) {
+                const int isucc = iord[*nrmax - 1];
+                if (errmax <= elist[isucc]) break;
+                iord[*nrmax] = isucc;
+                --*nrmax;
+            }
+        }
+        int jupbn = last;
+        if (last > (limit / 2 + 2)) jupbn = limit + 3 - last;
+        const double errmin = elist[last];
+        const int jbnd = jupbn - 1;
+        const int ibeg = *nrmax + 1;
+        bool placed = false;
+        for (int i = ibeg; i <= jbnd && !placed; ++i) {
+            int isucc = iord[i];
+            if (errmax >= elist[isucc]) {
+                iord[i - 1] = *maxerr;
+                int k = jbnd;
+                bool inserted = false;
+                for (int j = i; j <= jbnd; ++j) {
+                    isucc = iord[k];
+                    if (errmin < elist[isucc]) { iord[k + 1] = last; inserted = true; break; }
+                    iord[k + 1] = isucc;
+                    --k;
+                }
+                if (!inserted) iord[i] = last;
+                placed = true;
+            } else {
+                iord[i - 1] = isucc;
+            }
+        }
+        if (!placed) { iord[jbnd] = *maxerr; iord[jupbn] = last; }
+    }
+    *maxerr = iord[*nrmax];
+    *ermax = elist[*maxerr];
+}
+
+// QUADPACK dqelg (Wynn epsilon algorithm; epstab 1-based, 52 usable entries)
+__device__ inline void dqelg(int* n, double* epstab, double* result, double* abserr, double* res3la, int* nres) {
+    const double epmach = DBL_EPSILON, oflow = DBL_MAX;
+    const int limexp = 50;
+    ++*nres;
+    *abserr = oflow;
+    *result = epstab[*n];
+    if (*n >= 3) {
+        epstab[*n + 2] = epstab[*n];
+        const int newelm = (*n - 1) / 2;
+        epstab[*n] = oflow;
+        const int num = *n;
+        int k1 = *n;
+        for (int i = 1; i <= newelm; ++i) {
+            const int k2 = k1 - 1, k3 = k1 - 2;
+            double res = epstab[k1 + 2];
+            const double e0 = epstab[k3], e1 = epstab[k2], e2 = res;
+            const double e1abs = fabs(e1);
+            const double delta2 = e2 - e1, err2 = fabs(delta2), tol2 = fmax(fabs(e2), e1abs) * epmach;
+            const double delta3 = e1 - e0, err3 = fabs(delta3), tol3 = fmax(e1abs, fabs(e0)) * epmach;
+            if (err2 <= tol2 && err3 <= tol3) {
+                *result = res;
+                *abserr = fmax(err2 + err3, 5.0 * epmach * fabs(res));
+                return;
+            }
+            const double e3 = epstab[k1];
+            epstab[k1] = e1;
+            const double delta1 = e1 - e3, err1 = fabs(delta1), tol1 = fmax(e1abs, fabs(e3)) * epmach;
+            if (err1 <= tol1 || err2 <= tol2 || err3 <= tol3) { *n = i + i - 1; break; }
+            const double ss = 1.0 / delta1 + 1.0 / delta2 - 1.0 / delta3;
+            const double epsinf = fabs(ss * e1);
+            if (epsinf <= 1e-4) { *n = i + i - 1; break; }
+            res = e1 + 1.0 / ss;
+            epstab[k1] = res;
+            k1 -= 2;
+            const double error = err2 + fabs(res - e2) + err3;
+            if (error <= *abserr) { *abserr = error; *result = res; }
+        }
+        if (*n == limexp) *n = 2 * (limexp / 2) - 1;
+        int ib = ((num / 2) * 2 == num) ? 2 : 1;
+        const int ie = newelm + 1;
+        for (int i = 1; i <= ie; ++i) { const int ib2 = ib + 2; epstab[ib] = epstab[ib2]; ib = ib2; }
+        if (num != *n) {
+            int indx = num - *n + 1;
+            for (int i = 1; i <= *n; ++i) { epstab[i] = epstab[indx]; ++indx; }
+        }
+        if (*nres < 4) {
+            res3la[*nres] = *result;
+            *abserr = oflow;
+        } else {
+            *abserr = fabs(*result - res3la[3]) + fabs(*result - res3la[2]) + fabs(*result - res3la[1]);
+            res3la[1] = res3la[2]; res3la[2] = res3la[3]; res3la[3] = *result;
+        }
+    }
+    *abserr = fmax(*abserr, 5.0 * epmach * fabs(*result));
+}
+
+// The adaptive part of dqagse, entered only when the first panel is not accepted.
+__device__ __noinline__ void dqagse_adaptive(double rate, double a, double b, const GK21 first, double* result_out,
+                                             double* abserr_out) {
+    constexpr int LIMIT = 50;
+    const double epsabs = 1.49e-8, epsrel = 1.49e-8;
+    const double epmach = DBL_EPSILON, uflow = DBL_MIN, oflow = DBL_MAX;
+    double alist[LIMIT + 2], blist[LIMIT + 2], rlist[LIMIT + 2], elist[LIMIT + 2], rlist2[53], res3la[4];
+    int iord[LIMIT + 2];
+    for (int i = 0; i < LIMIT + 2; ++i) iord[i] = 0;
+    double result = first.result, abserr = oflow;
+    const double defabs = first.resabs;
+    const double dres = fabs(result);
+    double errbnd;
+    int ier = 0, ierro = 0, last;
+    alist[1] = a; blist[1] = b; rlist[1] = result; elist[1] = first.abserr; iord[1] = 1;
+    double errmax = first.abserr, area = result, errsum = first.abserr, small = 0.0, erlarg = 0.0, ertest = 0.0,
+           correc = 0.0;
+    int maxerr = 1, nrmax = 1, nres = 0, numrl2 = 2, ktmin = 0;
+    bool extrap = false, noext = false;
+    int iroff1 = 0, iroff2 = 0, iroff3 = 0;
+    const int ksgn = (dres >= (1.0 - 50.0 * epmach) * defabs) ? 1 : -1;
+    rlist2[1] = result;
+    bool sum_lists = false;  // QUADPACK label 115
+    for (last = 2; last <= LIMIT; ++last) {
+        const double a1 = alist[maxerr], b1 = 0.5 * (alist[maxerr] + blist[maxerr]), a2 = b1, b2 = blist[maxerr];
+        const double erlast = errmax;
+        const GK21 g1 = dqk21(rate, a1, b1), g2 = dqk21(rate, a2, b2);
+        const double area1 = g1.result, area2 = g2.result, error1 = g1.abserr, error2 = g2.abserr;
+        const double area12 = area1 + area2, erro12 = error1 + error2;
+        errsum = errsum + erro12 - errmax;
+        area = area + area12 - rlist[maxerr];
+        if (g1.resasc != error1 && g2.resasc != error2) {
+            if (fabs(rlist[maxerr] - area12) <= 1e-5 * fabs(area12) && erro12 >= 0.99 * errmax) {
+                if (extrap) ++iroff2; else ++iroff1;
+            }
+            if (last > 10 && erro12 > errmax) ++iroff3;
+        }
+        rlist[maxerr] = area1;
+        rlist[last] = area2;
+        errbnd = fmax(epsabs, epsrel * fabs(area));
+        if (iroff1 + iroff2 >= 10 || iroff3 >= 20) ier = 2;
+        if (iroff2 >= 5) ierro = 3;
+        if (last == LIMIT) ier = 1;
+        if (fmax(fabs(a1), fabs(b2)) <= (1.0 + 100.0 * epmach) * (fabs(a2) + 1000.0 * uflow)) ier = 4;
+        if (error2 > error1) {
+            alist[maxerr] = a2; alist[last] = a1; blist[last] = b1;
+            rlist[maxerr] = area2; rlist[last] = area1;
+            elist[maxerr] = error2; elist[last] = error1;
+        } else {
+            alist[last] = a2; blist[maxerr] = b1; blist[last] = b2;
+            elist[maxerr] = error1; elist[last] = error2;
+        }
+        dqpsrt(LIMIT, last, &maxerr, &errmax, elist, iord, &nrmax);
+        if (errsum <= errbnd) { sum_lists = true; break; }
+        if (ier != 0) break;
+        if (last == 2) {
+            small = fabs(b - a) * 0.375;
+            erlarg = errsum;
+            ertest = errbnd;
+            rlist2[2] = area;
+            continue;
+        }
+        if (noext) continue;
+        erlarg -= erlast;
+        if (fabs(b1 - a1) > small) erlarg += erro12;
+        if (!extrap) {
+            if (fabs(blist[maxerr] - alist[maxerr]) > small) continue;
+            extrap = true;
+            nrmax = 2;
+        }
+        if (ierro != 3 && erlarg > ertest) {
+            bool found = false;
+            const int id = nrmax;
+            int jupbnd = last;
+            if (last > (2 + LIMIT / 2)) jupbnd = LIMIT + 3 - last;
+            for (int k = id; k <= jupbnd; ++k) {
+                maxerr = iord[nrmax];
+                errmax = elist[maxerr];
+                if (fabs(blist[maxerr] - alist[maxerr]) > small) { found = true; break; }
+                ++nrmax;
+            }
+            if (found) continue;
+        }
+        ++numrl2;
+        rlist2[numrl2] = area;
+        double reseps, abseps;
+        dqelg(&numrl2, rlist2, &reseps, &abseps, res3la, &nres);
+        ++ktmin;
+        if (ktmin > 5 && abserr < 1e-3 * errsum) ier = 5;
+        if (abseps < abserr) {
+            ktmin = 0;
+            abserr = abseps;
+            result = reseps;
+            correc = erlarg;
+            ertest = fmax(epsabs, epsrel * fabs(reseps));
+            if (abserr <= ertest) break;
+        }
+        if (numrl2 == 1) noext = true;
+        if (ier == 5) break;
+        maxerr = iord[1];
+        errmax = elist[maxerr];
+        nrmax = 1;
+        extrap = false;
+        small *= 0.5;
+        erlarg = errsum;
+    }
+    if (last > LIMIT) last = LIMIT;
+    if (!sum_lists) {  // QUADPACK label 100
+        if (abserr == oflow) {
+            sum_lists = true;
+        } else if (ier + ierro != 0) {
+            if (ierro == 3) abserr += correc;
+            if (ier == 0) ier = 3;
+            if (result != 0.0 && area != 0.0) {
+                if (abserr / fabs(result) > errsum / fabs(area)) sum_lists = true;
+            } else if (abserr > errsum) {
+                sum_lists = true;
+            }
+        }
+        // label 110 (divergence test) only changes ier, which is not reported here
+        (void)ksgn;
+    }
+    if (sum_lists) {
+        result = 0.0;
+        for (int k = 1; k <= last; ++k) result += rlist[k];
+        abserr = errsum;
+    }
+    *result_out = result;
+    *abserr_out = abserr;
+}
+
+// scipy.integrate.quad(get_townsend_pi, a, b, args=(rate)) -> (integral, abserr)
+__device__ __forceinline__ void quad_townsend(double a, double b, double rate, double& result, double& abserr) {
+    const double epsabs = 1.49e-8, epsrel = 1.49e-8, epmach = DBL_EPSILON;
+    const GK21 g = dqk21(rate, a, b);
+    result = g.result;
+    abserr = g.abserr;
+    const double errbnd = fmax(epsabs, epsrel * fabs(g.result));
+    const bool roundoff = (g.abserr <= 100.0 * epmach * g.resabs && g.abserr > errbnd);  // ier = 2
+    const bool accept = roundoff || (g.abserr <= errbnd && g.abserr != g.resasc) || g.abserr == 0.0;
+    if (!accept) dqagse_adaptive(rate, a, b, g, &result, &abserr);
+}
+
+// Closed form: int_a^b 16 r^2 t exp(-4 r t) dt = g(4rb) - g(4ra), g(x) = 1 - (1+x) exp(-x); series for small x.
+__device__ __forceinline__ double g_one_minus(double x) {
+    if (x < 0.1) {
+        double term = x * x * 0.5, sum = 0.0;
+        for (int k = 2; k < 40; ++k) {
+            const double add = term * (double)(k - 1);
+            sum += (k & 1) ? -add : add;
+            if (add <= 1e-20 * fabs(sum)) break;
+            term = term * x / (double)(k + 1);
+        }
+        return sum;
+    }
+    return 1.0 - (1.0 + x) * exp(-x);
+}
+__device__ __forceinline__ double integral_closed(double a, double b, double r) {
+    return g_one_minus(4.0 * r * b) - g_one_minus(4.0 * r * a);
+}
+
+}  // namespace tphip

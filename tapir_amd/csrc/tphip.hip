@@ -1,0 +1,545 @@
+// tphip.hip -- C ABI (include/tphip.h) over the gfx950 kernels.  Host side only does validation, the
+// one-off tree compilation, table uploads and kernel launches; there is no CPU compute path.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gtr_model.hpp"
+#include "pi_kernels.hpp"
+#include "site_rate_kernel.hpp"
+#include "tphip.h"
+#include "tree_program.hpp"
+
+using namespace tphip;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(TPHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+constexpr int kProfileRing = 1024;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T>& h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess) return e;
+        if (h.empty()) return hipSuccess;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    }
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// small RAII set of device buffers for the host-pointer conveniences
+struct Scratch {
+    std::vector<void*> bufs;
+    ~Scratch() { for (void* q : bufs) if (q) (void)hipFree(q); }
+    template <typename T> T* get(size_t count) {
+        void* q = nullptr;
+        if (hipMalloc(&q, (count ? count : 1) * sizeof(T)) != hipSuccess) return nullptr;
+        bufs.push_back(q);
+        return (T*)q;
+    }
+};
+}  // namespace
+
+struct tphip_plan {
+    int32_t device = 0;
+    int32_t ntaxa = 0;
+    int64_t nloci = 0, ncols = 0;
+    int32_t T = 0, n_t = 0, n_i = 0, integ_mode = 0, threshold = 0, round_decimals = -1;
+    double correction = 1.0;
+    TreeProgram prog;
+    std::vector<int64_t> h_offsets;
+    int64_t n_site_chunks = 0, n_pi_chunks = 0;
+    DevBuf<TreeOp> d_ops;
+    DevBuf<LocusModel> d_models;
+    DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
+    DevBuf<int32_t> d_site_chunk_locus, d_site_chunk_index, d_pi_chunk_locus, d_pi_chunk_index, d_times, d_intervals;
+    DevBuf<unsigned long long> d_evals;
+    // workspace layout (bytes)
+    size_t ws_work_cols = 0, ws_work_count = 0, ws_partial = 0, ws_total = 0;
+    // profiling
+    bool profile = false;
+    std::vector<hipEvent_t> ev;  // 4 events per slot: site start/stop, pi start/stop
+    int ev_used = 0;
+    double acc_site_ms = 0, acc_pi_ms = 0;
+    int64_t acc_launches = 0;
+};
+
+extern "C" {
+
+int tphip_version(void) { return TPHIP_VERSION; }
+
+const char* tphip_last_error(void) { return g_err.c_str(); }
+
+int tphip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int tphip_plan_destroy(tphip_plan* plan) {
+    if (!plan) return TPHIP_OK;
+    (void)hipSetDevice(plan->device);
+    plan->d_ops.release(); plan->d_models.release(); plan->d_offsets.release();
+    plan->d_locus_pichunk_offsets.release(); plan->d_site_chunk_locus.release(); plan->d_site_chunk_index.release();
+    plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
+    plan->d_intervals.release(); plan->d_evals.release();
+    for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
+    delete plan;
+    return TPHIP_OK;
+}
+
+int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
+    if (!d || !out) return fail(TPHIP_ERR_INVALID, "null plan descriptor");
+    *out = nullptr;
+    int ndev = tphip_device_count();
+    if (ndev <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (d->device < 0 || d->device >= ndev) return fail(TPHIP_ERR_INVALID, "device ordinal out of range");
+    if (d->ntaxa < 2) return fail(TPHIP_ERR_INVALID, "ntaxa must be >= 2");
+    if (!d->parent || !d->branch_len || !d->leaf_taxon) return fail(TPHIP_ERR_INVALID, "null tree arrays");
+    if (d->nloci < 1 || !d->locus_offsets || !d->pi || !d->exch) return fail(TPHIP_ERR_INVALID, "null or empty locus arrays");
+    if (d->T < 0 || d->n_t < 0 || d->n_i < 0) return fail(TPHIP_ERR_INVALID, "negative schedule size");
+    if ((d->n_t && !d->times) || (d->n_i && !d->intervals)) return fail(TPHIP_ERR_INVALID, "null times/intervals");
+    if (!(d->correction > 0.0)) return fail(TPHIP_ERR_INVALID, "correction must be > 0");
+    if (d->integ_mode != TPHIP_INTEG_QUADPACK && d->integ_mode != TPHIP_INTEG_CLOSED)
+        return fail(TPHIP_ERR_INVALID, "unknown integ_mode");
+    for (int i = 0; i < d->n_t; ++i)
+        if (d->times[i] < 0 || d->times[i] >= d->T)  // numpy would raise IndexError (tapir/compute.py:78)
+            return fail(TPHIP_ERR_INVALID, "a --times value is outside 0..T-1 (index out of bounds for the net PI vector)");
+    for (int i = 0; i < d->n_i; ++i)
+        if (!(d->intervals[2 * i] < d->intervals[2 * i + 1]))  // assert at tapir/compute.py:90-91
+            return fail(TPHIP_ERR_INVALID, "Start time is sooner than end time in an interval");
+    if (d->locus_offsets[0] != 0) return fail(TPHIP_ERR_INVALID, "locus_offsets[0] must be 0");
+    for (int64_t l = 0; l < d->nloci; ++l) {
+        if (d->locus_offsets[l + 1] < d->locus_offsets[l]) return fail(TPHIP_ERR_INVALID, "locus_offsets not monotone");
+        for (int k = 0; k < 4; ++k)
+            if (!(d->pi[l * 4 + k] > 0.0)) return fail(TPHIP_ERR_INVALID, "base frequencies must be > 0");
+        for (int k = 0; k < 6; ++k)
+            if (!(d->exch[l * 6 + k] >= 0.0)) return fail(TPHIP_ERR_INVALID, "exchangeabilities must be >= 0");
+    }
+    const int64_t ncols = d->locus_offsets[d->nloci];
+    if (ncols >= (int64_t)1 << 31) return fail(TPHIP_ERR_INVALID, "more than 2^31-1 columns in one batch");
+
+    tphip_plan* p = new tphip_plan();
+    p->device = d->device; p->ntaxa = d->ntaxa; p->nloci = d->nloci; p->ncols = ncols;
+    p->T = d->T; p->n_t = d->n_t; p->n_i = d->n_i; p->integ_mode = d->integ_mode;
+    p->threshold = d->threshold; p->round_decimals = d->round_decimals; p->correction = d->correction;
+    std::string terr = build_tree_program(d->ntaxa, d->nnodes, d->parent, d->branch_len, d->leaf_taxon, &p->prog);
+    if (!terr.empty()) { delete p; return fail(TPHIP_ERR_INVALID, "tree: " + terr); }
+    const size_t lds_bytes = (64 + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    if (lds_bytes > 160 * 1024) { delete p; return fail(TPHIP_ERR_INVALID, "tree needs a deeper LDS stack than 160 KiB allows"); }
+    p->h_offsets.assign(d->locus_offsets, d->locus_offsets + d->nloci + 1);
+
+    // chunk tables: 64-column chunks for the optimiser, 1024-column chunks for classification and PI
+    std::vector<int32_t> scl, sci, pcl, pci;
+    std::vector<int64_t> lpo(d->nloci + 1, 0);
+    for (int64_t l = 0; l < d->nloci; ++l) {
+        const int64_t S = p->h_offsets[l + 1] - p->h_offsets[l];
+        for (int64_t c = 0; c * kSiteBlock < S; ++c) { scl.push_back((int32_t)l); sci.push_back((int32_t)c); }
+        for (int64_t c = 0; c * kPiChunk < S; ++c) { pcl.push_back((int32_t)l); pci.push_back((int32_t)c); }
+        lpo[l + 1] = (int64_t)pcl.size();
+    }
+    p->n_site_chunks = (int64_t)scl.size();
+    p->n_pi_chunks = (int64_t)pcl.size();
+
+    hipError_t e = hipSetDevice(d->device);
+    std::vector<int32_t> times(d->times, d->times + d->n_t), iv(d->intervals, d->intervals + 2 * (size_t)d->n_i);
+    DevBuf<double> d_pi, d_exch;
+    std::vector<double> hpi(d->pi, d->pi + 4 * (size_t)d->nloci), hex(d->exch, d->exch + 6 * (size_t)d->nloci);
+    if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
+    if (e == hipSuccess) e = p->d_offsets.upload(p->h_offsets);
+    if (e == hipSuccess) e = p->d_locus_pichunk_offsets.upload(lpo);
+    if (e == hipSuccess) e = p->d_site_chunk_locus.upload(scl);
+    if (e == hipSuccess) e = p->d_site_chunk_index.upload(sci);
+    if (e == hipSuccess) e = p->d_pi_chunk_locus.upload(pcl);
+    if (e == hipSuccess) e = p->d_pi_chunk_index.upload(pci);
+    if (e == hipSuccess) e = p->d_times.upload(times);
+    if (e == hipSuccess) e = p->d_intervals.upload(iv);
+    if (e == hipSuccess) e = p->d_models.alloc((size_t)d->nloci);
+    if (e == hipSuccess) e = p->d_evals.alloc(1);
+    if (e == hipSuccess) e = hipMemset(p->d_evals.p, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = d_pi.upload(hpi);
+    if (e == hipSuccess) e = d_exch.upload(hex);
+    if (e == hipSuccess) {
+        const int bs = 128;
+        gtr_setup_kernel<<<dim3((unsigned)((d->nloci + bs - 1) / bs)), dim3(bs)>>>(d_pi.p, d_exch.p, d->nloci, p->d_models.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    d_pi.release();
+    d_exch.release();
+    if (e != hipSuccess) {
+        std::string m = std::string("plan setup: ") + hipGetErrorString(e);
+        tphip_plan_destroy(p);
+        return fail(TPHIP_ERR_HIP, m);
+    }
+    // workspace layout
+    size_t off = 0;
+    p->ws_work_cols = off; off = align_up(off + sizeof(int32_t) * (size_t)ncols, 256);
+    p->ws_work_count = off; off = align_up(off + sizeof(int32_t) * (size_t)d->nloci, 256);
+    p->ws_partial = off; off = align_up(off + sizeof(double) * (size_t)p->n_pi_chunks * (size_t)(d->T + 2 * d->n_i), 256);
+    p->ws_total = off + 256;
+    *out = p;
+    return TPHIP_OK;
+}
+
+int32_t tphip_plan_table_width(const tphip_plan* p) { return p ? p->T + p->n_t + 2 * p->n_i : 0; }
+int64_t tphip_plan_ncols(const tphip_plan* p) { return p ? p->ncols : 0; }
+size_t tphip_plan_workspace_bytes(const tphip_plan* p) { return p ? p->ws_total : 0; }
+double tphip_plan_chrono_length(const tphip_plan* p) { return p ? p->prog.chrono_length : 0.0; }
+int32_t tphip_plan_stack_depth(const tphip_plan* p) { return p ? p->prog.stack_depth : 0; }
+
+int tphip_plan_get_models(const tphip_plan* p, double* lam, double* U, double* Uinv, double* kappa) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<LocusModel> h((size_t)p->nloci);
+    HIP_TRY(hipMemcpy(h.data(), p->d_models.p, sizeof(LocusModel) * h.size(), hipMemcpyDeviceToHost));
+    for (int64_t l = 0; l < p->nloci; ++l) {
+        if (lam) memcpy(lam + 4 * l, h[l].lam, sizeof(double) * 4);
+        if (U) memcpy(U + 16 * l, h[l].U, sizeof(double) * 16);
+        if (Uinv) memcpy(Uinv + 16 * l, h[l].Ui, sizeof(double) * 16);
+        if (kappa) kappa[l] = h[l].kappa;
+    }
+    return TPHIP_OK;
+}
+
+int tphip_profile_enable(tphip_plan* p, int32_t on) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    if (on && p->ev.empty()) {
+        p->ev.resize(4 * kProfileRing);
+        for (auto& e : p->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    p->profile = on != 0;
+    return TPHIP_OK;
+}
+
+static int profile_drain(tphip_plan* p) {
+    for (int s = 0; s < p->ev_used; ++s) {
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(p->ev[4 * s + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev[4 * s + 0], p->ev[4 * s + 1]));
+        p->acc_site_ms += ms;
+        HIP_TRY(hipEventSynchronize(p->ev[4 * s + 3]));
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev[4 * s + 2], p->ev[4 * s + 3]));
+        p->acc_pi_ms += ms;
+        ++p->acc_launches;
+    }
+    p->ev_used = 0;
+    return TPHIP_OK;
+}
+
+int tphip_profile_read(tphip_plan* p, double* site_ms, double* pi_ms, int64_t* launches, int32_t reset) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = profile_drain(p);
+    if (rc) return rc;
+    if (site_ms) *site_ms = p->acc_site_ms;
+    if (pi_ms) *pi_ms = p->acc_pi_ms;
+    if (launches) *launches = p->acc_launches;
+    if (reset) { p->acc_site_ms = p->acc_pi_ms = 0; p->acc_launches = 0; }
+    return TPHIP_OK;
+}
+
+int tphip_last_eval_count(tphip_plan* p, int64_t* evals) {
+    if (!p || !evals) return fail(TPHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, p->d_evals.p, sizeof v, hipMemcpyDeviceToHost));
+    *evals = (int64_t)v;
+    return TPHIP_OK;
+}
+
+// ---- launches ------------------------------------------------------------------------------------
+
+static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_rate, double* d_subst, double* d_lnl,
+                             uint8_t* d_flag, int32_t* d_nres, void* ws, hipStream_t st, int slot) {
+    int32_t* work_cols = (int32_t*)((char*)ws + p->ws_work_cols);
+    int32_t* work_count = (int32_t*)((char*)ws + p->ws_work_count);
+    ClassifyParams C;
+    C.states = d_states; C.ncols_total = p->ncols; C.ntaxa = p->ntaxa; C.models = p->d_models.p;
+    C.locus_offsets = p->d_offsets.p; C.chunk_locus = p->d_pi_chunk_locus.p; C.chunk_index = p->d_pi_chunk_index.p;
+    C.rate = d_rate; C.subst = d_subst; C.lnl = d_lnl; C.flag = d_flag; C.nres = d_nres;
+    C.chrono_length = p->prog.chrono_length;
+    if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
+    if (p->n_pi_chunks > 0) {
+        classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
+        compact_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
+    }
+    HIP_TRY(hipMemsetAsync(p->d_evals.p, 0, sizeof(unsigned long long), st));
+    SiteParams S;
+    S.states = d_states; S.ncols_total = p->ncols; S.models = p->d_models.p; S.ops = p->d_ops.p;
+    S.nops = (int32_t)p->prog.ops.size(); S.stack_depth = p->prog.stack_depth; S.chrono_length = p->prog.chrono_length;
+    S.locus_offsets = p->d_offsets.p; S.chunk_locus = p->d_site_chunk_locus.p; S.chunk_index = p->d_site_chunk_index.p;
+    S.work_cols = work_cols; S.work_count = work_count;
+    S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
+    const size_t lds = (64 + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    if (p->n_site_chunks > 0)
+        site_rate_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds, st>>>(S);
+    if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));
+    HIP_TRY(hipGetLastError());
+    return TPHIP_OK;
+}
+
+static int launch_pi_tables(tphip_plan* p, const double* d_rates, const int32_t* d_nres, double* d_tables, void* ws,
+                            hipStream_t st, int slot) {
+    PiParams Q;
+    Q.rates = d_rates; Q.nres = d_nres; Q.locus_offsets = p->d_offsets.p;
+    Q.chunk_locus = p->d_pi_chunk_locus.p; Q.chunk_index = p->d_pi_chunk_index.p;
+    Q.T = p->T; Q.intervals = p->d_intervals.p; Q.n_i = p->n_i; Q.integ_mode = p->integ_mode;
+    Q.correction = p->correction; Q.threshold = p->threshold;
+    Q.round_scale = (p->round_decimals >= 0) ? std::pow(10.0, (double)p->round_decimals) : 0.0;
+    Q.partial = (double*)((char*)ws + p->ws_partial);
+    if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 2], st));
+    if (p->n_pi_chunks > 0) pi_partial_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(Q);
+    pi_reduce_kernel<<<dim3((unsigned)p->nloci), dim3(64), 0, st>>>(Q.partial, p->d_locus_pichunk_offsets.p, p->T,
+                                                                   p->d_times.p, p->n_t, p->n_i, d_tables);
+    if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 3], st));
+    HIP_TRY(hipGetLastError());
+    return TPHIP_OK;
+}
+
+static int take_slot(tphip_plan* p) {
+    if (!p->profile) return -1;
+    if (p->ev_used >= kProfileRing) {
+        if (profile_drain(p)) return -1;
+    }
+    return p->ev_used++;
+}
+
+int tphip_run_dev(tphip_plan* p, const uint8_t* d_states, double* d_rate, double* d_subst, double* d_lnl, uint8_t* d_flag,
+                  int32_t* d_nres, double* d_tables, void* ws, size_t ws_bytes, void* stream) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (!d_states || !d_rate || !d_subst || !d_lnl || !d_flag || !d_nres || !d_tables || !ws)
+        return fail(TPHIP_ERR_INVALID, "null device pointer");
+    if (ws_bytes < p->ws_total) return fail(TPHIP_ERR_WORKSPACE, "workspace smaller than tphip_plan_workspace_bytes()");
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slot = take_slot(p);
+    int rc = launch_site_rates(p, d_states, d_rate, d_subst, d_lnl, d_flag, d_nres, ws, st, slot);
+    if (rc) return rc;
+    return launch_pi_tables(p, d_rate, d_nres, d_tables, ws, st, slot);
+}
+
+int tphip_site_rates_dev(tphip_plan* p, const uint8_t* d_states, double* d_rate, double* d_subst, double* d_lnl,
+                         uint8_t* d_flag, int32_t* d_nres, void* ws, size_t ws_bytes, void* stream) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (!d_states || !d_rate || !d_subst || !d_lnl || !d_flag || !d_nres || !ws)
+        return fail(TPHIP_ERR_INVALID, "null device pointer");
+    if (ws_bytes < p->ws_total) return fail(TPHIP_ERR_WORKSPACE, "workspace smaller than tphip_plan_workspace_bytes()");
+    HIP_TRY(hipSetDevice(p->device));
+    int slot = take_slot(p);
+    int rc = launch_site_rates(p, d_states, d_rate, d_subst, d_lnl, d_flag, d_nres, ws, (hipStream_t)stream, slot);
+    if (rc == 0 && slot >= 0) {  // keep the pi event pair of this slot valid (zero-length)
+        HIP_TRY(hipEventRecord(p->ev[4 * slot + 2], (hipStream_t)stream));
+        HIP_TRY(hipEventRecord(p->ev[4 * slot + 3], (hipStream_t)stream));
+    }
+    return rc;
+}
+
+int tphip_pi_tables_dev(tphip_plan* p, const double* d_rates, const int32_t* d_nres, double* d_tables, void* ws,
+                        size_t ws_bytes, void* stream) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (!d_rates || !d_tables || !ws) return fail(TPHIP_ERR_INVALID, "null device pointer");
+    if (ws_bytes < p->ws_total) return fail(TPHIP_ERR_WORKSPACE, "workspace smaller than tphip_plan_workspace_bytes()");
+    HIP_TRY(hipSetDevice(p->device));
+    int slot = take_slot(p);
+    if (slot >= 0) {
+        HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], (hipStream_t)stream));
+        HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], (hipStream_t)stream));
+    }
+    return launch_pi_tables(p, d_rates, d_nres, d_tables, ws, (hipStream_t)stream, slot);
+}
+
+int tphip_townsend_pi_dense_dev(int32_t device, const double* d_rates, int64_t n, const double* d_times, int32_t n_times,
+                                double* d_out, void* stream) {
+    if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (n < 0 || n_times < 0 || (n && n_times && (!d_rates || !d_out || !d_times))) return fail(TPHIP_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    if (n && n_times) {
+        townsend_dense_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(d_rates, n, d_times,
+                                                                                                    n_times, d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return TPHIP_OK;
+}
+
+int tphip_quad_townsend_dev(int32_t device, const double* d_rates, int64_t n, double a, double b, int32_t integ_mode,
+                            double* d_integral, double* d_abserr, void* stream) {
+    if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (n < 0 || (n && (!d_rates || !d_integral || !d_abserr))) return fail(TPHIP_ERR_INVALID, "bad arguments");
+    if (!(a < b)) return fail(TPHIP_ERR_INVALID, "Start time is sooner than end time in an interval");
+    if (integ_mode != TPHIP_INTEG_QUADPACK && integ_mode != TPHIP_INTEG_CLOSED) return fail(TPHIP_ERR_INVALID, "unknown integ_mode");
+    HIP_TRY(hipSetDevice(device));
+    if (n) {
+        quad_sites_kernel<<<dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream>>>(d_rates, n, a, b, integ_mode,
+                                                                                                d_integral, d_abserr);
+        HIP_TRY(hipGetLastError());
+    }
+    return TPHIP_OK;
+}
+
+int tphip_state_histogram_dev(tphip_plan* p, const uint8_t* d_states, int64_t* d_hist, void* stream) {
+    if (!p || !d_states || !d_hist) return fail(TPHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    state_histogram_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, (hipStream_t)stream>>>(
+        d_states, p->ncols, p->ntaxa, p->d_offsets.p, (unsigned long long*)d_hist);
+    HIP_TRY(hipGetLastError());
+    return TPHIP_OK;
+}
+
+// ---- host-pointer wrappers -------------------------------------------------------------------------
+
+namespace {
+struct HostRun {
+    tphip_plan* p;
+    uint8_t* states = nullptr; double *rate = nullptr, *subst = nullptr, *lnl = nullptr, *tables = nullptr;
+    uint8_t* flag = nullptr; int32_t* nres = nullptr; void* ws = nullptr;
+    explicit HostRun(tphip_plan* plan) : p(plan) {}
+    ~HostRun() {
+        for (void* q : {(void*)states, (void*)rate, (void*)subst, (void*)lnl, (void*)tables, (void*)flag, (void*)nres, ws})
+            if (q) (void)hipFree(q);
+    }
+};
+}  // namespace
+
+static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in, const int32_t* nres_in, double* rate,
+                    double* subst, double* lnl, uint8_t* flag, int32_t* nres, double* tables, bool do_site, bool do_pi) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HostRun R(p);
+    const size_t n = (size_t)p->ncols, W = (size_t)tphip_plan_table_width(p);
+    HIP_TRY(hipMalloc((void**)&R.rate, sizeof(double) * (n ? n : 1)));
+    HIP_TRY(hipMalloc((void**)&R.nres, sizeof(int32_t) * (n ? n : 1)));
+    HIP_TRY(hipMalloc(&R.ws, p->ws_total));
+    if (do_site) {
+        if (!states || !rate || !subst || !lnl || !flag || !nres) return fail(TPHIP_ERR_INVALID, "null host pointer");
+        HIP_TRY(hipMalloc((void**)&R.states, n * (size_t)p->ntaxa + 1));
+        HIP_TRY(hipMalloc((void**)&R.subst, sizeof(double) * (n ? n : 1)));
+        HIP_TRY(hipMalloc((void**)&R.lnl, sizeof(double) * (n ? n : 1)));
+        HIP_TRY(hipMalloc((void**)&R.flag, n ? n : 1));
+        HIP_TRY(hipMemcpy(R.states, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice));
+        int rc = launch_site_rates(p, R.states, R.rate, R.subst, R.lnl, R.flag, R.nres, R.ws, nullptr, -1);
+        if (rc) return rc;
+    } else {
+        if (!rates_in) return fail(TPHIP_ERR_INVALID, "null host pointer");
+        HIP_TRY(hipMemcpy(R.rate, rates_in, sizeof(double) * n, hipMemcpyHostToDevice));
+        if (nres_in) HIP_TRY(hipMemcpy(R.nres, nres_in, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    }
+    if (do_pi) {
+        if (!tables) return fail(TPHIP_ERR_INVALID, "null host pointer");
+        HIP_TRY(hipMalloc((void**)&R.tables, sizeof(double) * W * (size_t)p->nloci + 8));
+        int rc = launch_pi_tables(p, R.rate, (do_site || nres_in) ? R.nres : nullptr, R.tables, R.ws, nullptr, -1);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (do_site) {
+        HIP_TRY(hipMemcpy(rate, R.rate, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(subst, R.subst, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(lnl, R.lnl, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(flag, R.flag, n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(nres, R.nres, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    }
+    if (do_pi) HIP_TRY(hipMemcpy(tables, R.tables, sizeof(double) * W * (size_t)p->nloci, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
+}
+
+int tphip_site_rates(tphip_plan* p, const uint8_t* states, double* rate, double* subst, double* lnl, uint8_t* flag,
+                     int32_t* nres) {
+    return host_run(p, states, nullptr, nullptr, rate, subst, lnl, flag, nres, nullptr, true, false);
+}
+
+int tphip_pi_tables(tphip_plan* p, const double* rates, const int32_t* nres, double* tables) {
+    return host_run(p, nullptr, rates, nres, nullptr, nullptr, nullptr, nullptr, nullptr, tables, false, true);
+}
+
+int tphip_run_fused(tphip_plan* p, const uint8_t* states, double* rate, double* subst, double* lnl, uint8_t* flag,
+                    int32_t* nres, double* tables) {
+    return host_run(p, states, nullptr, nullptr, rate, subst, lnl, flag, nres, tables, true, true);
+}
+
+int tphip_townsend_pi_dense(int32_t device, const double* rates, int64_t n, const double* times, int32_t n_times, double* out) {
+    if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (n < 0 || n_times < 0) return fail(TPHIP_ERR_INVALID, "bad arguments");
+    if (n == 0 || n_times == 0) return TPHIP_OK;
+    if (!rates || !times || !out) return fail(TPHIP_ERR_INVALID, "null host pointer");
+    HIP_TRY(hipSetDevice(device));
+    Scratch S;
+    double* d_r = S.get<double>((size_t)n);
+    double* d_t = S.get<double>((size_t)n_times);
+    double* d_o = S.get<double>((size_t)n * (size_t)n_times);
+    if (!d_r || !d_t || !d_o) return fail(TPHIP_ERR_HIP, "hipMalloc failed for the dense PI matrix");
+    HIP_TRY(hipMemcpy(d_r, rates, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_t, times, sizeof(double) * (size_t)n_times, hipMemcpyHostToDevice));
+    int rc = tphip_townsend_pi_dense_dev(device, d_r, n, d_t, n_times, d_o, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * (size_t)n * (size_t)n_times, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
+}
+
+int tphip_quad_townsend(int32_t device, const double* rates, int64_t n, double a, double b, int32_t integ_mode,
+                        double* integral, double* abserr) {
+    if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (n < 0) return fail(TPHIP_ERR_INVALID, "bad arguments");
+    if (n == 0) return TPHIP_OK;
+    if (!rates || !integral || !abserr) return fail(TPHIP_ERR_INVALID, "null host pointer");
+    HIP_TRY(hipSetDevice(device));
+    Scratch S;
+    double* d_r = S.get<double>((size_t)n);
+    double* d_i = S.get<double>((size_t)n);
+    double* d_e = S.get<double>((size_t)n);
+    if (!d_r || !d_i || !d_e) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_r, rates, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    int rc = tphip_quad_townsend_dev(device, d_r, n, a, b, integ_mode, d_i, d_e, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(integral, d_i, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(abserr, d_e, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
+}
+
+int tphip_state_histogram(tphip_plan* p, const uint8_t* states, int64_t* hist) {
+    if (!p || !states || !hist) return fail(TPHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    uint8_t* d_s = nullptr; int64_t* d_h = nullptr;
+    const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
+    HIP_TRY(hipMalloc((void**)&d_s, nb + 1));
+    if (hipMalloc((void**)&d_h, sizeof(int64_t) * 16 * (size_t)p->nloci) != hipSuccess) { (void)hipFree(d_s); return fail(TPHIP_ERR_HIP, "hipMalloc failed"); }
+    int rc = TPHIP_OK;
+    if (hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(TPHIP_ERR_HIP, "H2D failed");
+    if (!rc) rc = tphip_state_histogram_dev(p, d_s, d_h, nullptr);
+    if (!rc && hipMemcpy(hist, d_h, sizeof(int64_t) * 16 * (size_t)p->nloci, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(TPHIP_ERR_HIP, "D2H failed");
+    (void)hipFree(d_s);
+    (void)hipFree(d_h);
+    return rc;
+}
+
+}  // extern "C"

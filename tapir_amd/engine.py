@@ -1,0 +1,248 @@
+"""ctypes binding of libtphip.so (include/tphip.h) -- the MI355X site-rate + PI engine.
+
+This replaces, for every locus at once, what `worker()` does per locus in the reference
+(bin/tapir_compute.py:84-123): the HyPhy subprocess (Popen + JSON file round trip) and the numpy/scipy
+PI arithmetic.  There is deliberately no CPU fallback: if the shared library is missing, or no GPU is
+visible, every entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtphip.so")
+
+FLAG_OK, FLAG_FLAT, FLAG_SATURATED, FLAG_ZERO, FLAG_MAXIT = 0, 1, 2, 3, 4
+INTEG_QUADPACK, INTEG_CLOSED = 0, 1
+
+_vp = ctypes.c_void_p
+_i32, _i64, _f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+
+
+class TphipError(Exception):
+    """An error reported by libtphip (message from tphip_last_error)."""
+
+
+class PlanDesc(ctypes.Structure):
+    _fields_ = [("device", _i32), ("ntaxa", _i32), ("nnodes", _i32), ("parent", _vp), ("branch_len", _vp),
+                ("leaf_taxon", _vp), ("nloci", _i64), ("locus_offsets", _vp), ("pi", _vp), ("exch", _vp),
+                ("T", _i32), ("times", _vp), ("n_t", _i32), ("intervals", _vp), ("n_i", _i32),
+                ("integ_mode", _i32), ("correction", _f64), ("threshold", _i32), ("round_decimals", _i32)]
+
+
+# every symbol include/tphip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("tphip_version", ctypes.c_int, []),
+    ("tphip_last_error", ctypes.c_char_p, []),
+    ("tphip_device_count", ctypes.c_int, []),
+    ("tphip_plan_create", ctypes.c_int, [ctypes.POINTER(PlanDesc), ctypes.POINTER(_vp)]),
+    ("tphip_plan_destroy", ctypes.c_int, [_vp]),
+    ("tphip_plan_table_width", _i32, [_vp]),
+    ("tphip_plan_ncols", _i64, [_vp]),
+    ("tphip_plan_workspace_bytes", ctypes.c_size_t, [_vp]),
+    ("tphip_plan_chrono_length", _f64, [_vp]),
+    ("tphip_plan_stack_depth", _i32, [_vp]),
+    ("tphip_plan_get_models", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    ("tphip_site_rates_dev", ctypes.c_int, [_vp] * 8 + [ctypes.c_size_t, _vp]),
+    ("tphip_pi_tables_dev", ctypes.c_int, [_vp] * 5 + [ctypes.c_size_t, _vp]),
+    ("tphip_run_dev", ctypes.c_int, [_vp] * 9 + [ctypes.c_size_t, _vp]),
+    ("tphip_townsend_pi_dense_dev", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
+    ("tphip_quad_townsend_dev", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp, _vp]),
+    ("tphip_state_histogram_dev", ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    ("tphip_profile_enable", ctypes.c_int, [_vp, _i32]),
+    ("tphip_profile_read", ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_f64), ctypes.POINTER(_i64), _i32]),
+    ("tphip_last_eval_count", ctypes.c_int, [_vp, ctypes.POINTER(_i64)]),
+    ("tphip_site_rates", ctypes.c_int, [_vp] * 7),
+    ("tphip_pi_tables", ctypes.c_int, [_vp] * 4),
+    ("tphip_run_fused", ctypes.c_int, [_vp] * 8),
+    ("tphip_townsend_pi_dense", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp]),
+    ("tphip_quad_townsend", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp]),
+    ("tphip_state_histogram", ctypes.c_int, [_vp, _vp, _vp]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libtphip.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TphipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(the engine has no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise TphipError("libtphip error %d: %s" % (rc, load().tphip_last_error().decode("utf-8", "replace")))
+
+
+def device_count():
+    return load().tphip_device_count()
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    """Device pointer of a torch tensor, host pointer of a numpy array, or None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+class Plan:
+    """Tree program + per-locus GTR models + PI schedule on one device (tphip_plan_*).
+
+    parent / branch_len / leaf_taxon: post-order tree arrays (branch lengths already / correction).
+    locus_offsets: [L+1] column ranges; pi [L,4]; exch [L,6] in AC,AG,AT,CG,CT,GT order.
+    times / intervals: the --times and --intervals of bin/tapir_compute.py:27-33.
+    """
+
+    def __init__(self, ntaxa, parent, branch_len, leaf_taxon, locus_offsets, pi, exch, T, times, intervals,
+                 correction=1.0, threshold=3, round_decimals=4, integ_mode=INTEG_QUADPACK, device=0):
+        lib = load()
+        self._lib = lib
+        self._h = _vp()
+        self._keep = dict(parent=_np(parent, np.int32), blen=_np(branch_len, np.float64),
+                          leaf=_np(leaf_taxon, np.int32), off=_np(locus_offsets, np.int64),
+                          pi=_np(pi, np.float64).reshape(-1), exch=_np(exch, np.float64).reshape(-1),
+                          times=_np(times, np.int32).reshape(-1), iv=_np(intervals, np.int32).reshape(-1))
+        k = self._keep
+        self.nloci = len(k["off"]) - 1
+        if k["pi"].size != 4 * self.nloci or k["exch"].size != 6 * self.nloci:
+            raise TphipError("pi must be [L,4] and exch [L,6] for L = len(locus_offsets) - 1")
+        if k["iv"].size % 2:
+            raise TphipError("intervals must be (start, stop) pairs")
+        d = PlanDesc(device=device, ntaxa=ntaxa, nnodes=len(k["parent"]), parent=k["parent"].ctypes.data,
+                     branch_len=k["blen"].ctypes.data, leaf_taxon=k["leaf"].ctypes.data, nloci=self.nloci,
+                     locus_offsets=k["off"].ctypes.data, pi=k["pi"].ctypes.data, exch=k["exch"].ctypes.data, T=int(T),
+                     times=k["times"].ctypes.data, n_t=k["times"].size, intervals=k["iv"].ctypes.data,
+                     n_i=k["iv"].size // 2, integ_mode=integ_mode, correction=float(correction),
+                     threshold=int(threshold), round_decimals=int(round_decimals))
+        _check(lib.tphip_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
+        self.device = device
+        self.ntaxa = ntaxa
+        self.T, self.n_t, self.n_i = int(T), k["times"].size, k["iv"].size // 2
+        self.ncols = lib.tphip_plan_ncols(self._h)
+        self.width = lib.tphip_plan_table_width(self._h)
+        self.workspace_bytes = lib.tphip_plan_workspace_bytes(self._h)
+        self.chrono_length = lib.tphip_plan_chrono_length(self._h)
+        self.stack_depth = lib.tphip_plan_stack_depth(self._h)
+
+    def close(self):
+        if self._h:
+            self._lib.tphip_plan_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer path (numpy in, numpy out; the library does the PCIe copies) -------------
+    def site_rates(self, states):
+        """states: uint8 [ntaxa, ncols] masks.  Returns dict(rate, subst, lnl, flag, nres)."""
+        states = _np(states, np.uint8)
+        assert states.shape == (self.ntaxa, self.ncols), (states.shape, self.ntaxa, self.ncols)
+        n = self.ncols
+        out = dict(rate=np.empty(n), subst=np.empty(n), lnl=np.empty(n), flag=np.empty(n, np.uint8),
+                   nres=np.empty(n, np.int32))
+        _check(self._lib.tphip_site_rates(self._h, states.ctypes.data, out["rate"].ctypes.data, out["subst"].ctypes.data,
+                                          out["lnl"].ctypes.data, out["flag"].ctypes.data, out["nres"].ctypes.data))
+        return out
+
+    def pi_tables(self, rates, nres=None):
+        """rates: float64 [ncols] raw rates (rounding, /correction and cull are applied by the kernel).
+        Returns tables [L, W]."""
+        rates = _np(rates, np.float64)
+        assert rates.shape == (self.ncols,)
+        nres = None if nres is None else _np(nres, np.int32)
+        tables = np.empty((self.nloci, self.width))
+        _check(self._lib.tphip_pi_tables(self._h, rates.ctypes.data, _ptr(nres), tables.ctypes.data))
+        return tables
+
+    def run_fused(self, states):
+        states = _np(states, np.uint8)
+        assert states.shape == (self.ntaxa, self.ncols), (states.shape, self.ntaxa, self.ncols)
+        n = self.ncols
+        out = dict(rate=np.empty(n), subst=np.empty(n), lnl=np.empty(n), flag=np.empty(n, np.uint8),
+                   nres=np.empty(n, np.int32), tables=np.empty((self.nloci, self.width)))
+        _check(self._lib.tphip_run_fused(self._h, states.ctypes.data, out["rate"].ctypes.data, out["subst"].ctypes.data,
+                                         out["lnl"].ctypes.data, out["flag"].ctypes.data, out["nres"].ctypes.data,
+                                         out["tables"].ctypes.data))
+        return out
+
+    def state_histogram(self, states):
+        states = _np(states, np.uint8)
+        hist = np.empty((self.nloci, 16), np.int64)
+        _check(self._lib.tphip_state_histogram(self._h, states.ctypes.data, hist.ctypes.data))
+        return hist
+
+    def models(self):
+        L = self.nloci
+        lam, U, Ui, kappa = np.empty((L, 4)), np.empty((L, 4, 4)), np.empty((L, 4, 4)), np.empty(L)
+        _check(self._lib.tphip_plan_get_models(self._h, lam.ctypes.data, U.ctypes.data, Ui.ctypes.data, kappa.ctypes.data))
+        return lam, U, Ui, kappa
+
+    # ---- device-pointer path (torch tensors resident in HBM; nothing is copied or synchronised) --
+    def run_dev(self, d_states, d_rate, d_subst, d_lnl, d_flag, d_nres, d_tables, d_ws, stream=0):
+        _check(self._lib.tphip_run_dev(self._h, _ptr(d_states), _ptr(d_rate), _ptr(d_subst), _ptr(d_lnl), _ptr(d_flag),
+                                       _ptr(d_nres), _ptr(d_tables), _ptr(d_ws), d_ws.numel() * d_ws.element_size(),
+                                       stream))
+
+    def site_rates_dev(self, d_states, d_rate, d_subst, d_lnl, d_flag, d_nres, d_ws, stream=0):
+        _check(self._lib.tphip_site_rates_dev(self._h, _ptr(d_states), _ptr(d_rate), _ptr(d_subst), _ptr(d_lnl),
+                                              _ptr(d_flag), _ptr(d_nres), _ptr(d_ws),
+                                              d_ws.numel() * d_ws.element_size(), stream))
+
+    def pi_tables_dev(self, d_rates, d_nres, d_tables, d_ws, stream=0):
+        _check(self._lib.tphip_pi_tables_dev(self._h, _ptr(d_rates), _ptr(d_nres), _ptr(d_tables), _ptr(d_ws),
+                                             d_ws.numel() * d_ws.element_size(), stream))
+
+    def state_histogram_dev(self, d_states, d_hist, stream=0):
+        _check(self._lib.tphip_state_histogram_dev(self._h, _ptr(d_states), _ptr(d_hist), stream))
+
+    def profile_enable(self, on=True):
+        _check(self._lib.tphip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset=True):
+        a, b, n = _f64(), _f64(), _i64()
+        _check(self._lib.tphip_profile_read(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n), 1 if reset else 0))
+        return a.value, b.value, n.value
+
+    def last_eval_count(self):
+        n = _i64()
+        _check(self._lib.tphip_last_eval_count(self._h, ctypes.byref(n)))
+        return n.value
+
+
+def townsend_pi_dense(times, rates, device=0):
+    """tapir/compute.py:46-48 for a vector of times and a vector of rates -> (n_times, n) matrix (GPU)."""
+    rates = _np(rates, np.float64).reshape(-1)
+    times = _np(times, np.float64).reshape(-1)
+    out = np.empty((times.size, rates.size))
+    _check(load().tphip_townsend_pi_dense(device, rates.ctypes.data, rates.size, times.ctypes.data, times.size,
+                                          out.ctypes.data))
+    return out
+
+
+def quad_townsend(a, b, rates, integ_mode=INTEG_QUADPACK, device=0):
+    """tapir/compute.py:50-52 over a vector of rates -> (integral[n], abserr[n]) (GPU, dqagse emulation)."""
+    rates = _np(rates, np.float64).reshape(-1)
+    integral, abserr = np.empty(rates.size), np.empty(rates.size)
+    _check(load().tphip_quad_townsend(device, rates.ctypes.data, rates.size, float(a), float(b), integ_mode,
+                                      integral.ctypes.data, abserr.ctypes.data))
+    return integral, abserr

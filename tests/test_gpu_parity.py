@@ -1,0 +1,192 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): HIP path through the C ABI vs the CPU oracle,
+vs the reference's golden vectors, and size-independent properties at larger shapes.
+
+Tolerances (north_star: 1e-6 relative on per-site rates and PI integrals):
+  rate / lnL  GPU vs oracle   rel 1e-6 on columns whose flag is OK or ZERO (flat and saturated columns have
+                              no unique maximiser: their policy values are compared exactly by flag)
+  PI tables   GPU vs golden   rel 1e-12 (both are fp64 evaluations of the same closed-form expressions)
+  sum(error)  GPU vs golden   rel 1e-6 (QUADPACK's abserr is partly rounding noise)
+  KAT         GPU vs PhyDesign file  5e-5 absolute (the file holds 4 decimals)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL_RATE = 1e-6
+RTOL_PI = 1e-12
+
+
+def _engine():
+    from tapir_amd import engine
+    if engine.device_count() < 1:
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    return engine
+
+
+def _rel(a, b, floor=1e-300):
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def _plan_for(engine, c, T, times, intervals, correction=1.0, threshold=3, round_decimals=4, integ_mode=0):
+    ncols = c["states"].shape[1]
+    return engine.Plan(c["states"].shape[0], c["parent"], c["blen"], c["leaf"], [0, ncols], [c["pi"]], [c["exch"]],
+                       T, times, intervals, correction=correction, threshold=threshold,
+                       round_decimals=round_decimals, integ_mode=integ_mode)
+
+
+def test_chr1_918_site_rates_vs_phydesign_and_oracle(chr1_918, oracle):
+    """The reference's only stage-2 known-answer file, through the HIP kernel."""
+    engine = _engine()
+    c = chr1_918
+    plan = _plan_for(engine, c, 174, [10, 20, 50], [[0, 10]], correction=c["factor"])
+    got = plan.site_rates(c["states"])
+    ref = oracle.site_rates(c["states"], c["parent"], c["blen"], c["leaf"], c["pi"], c["exch"])
+    assert np.array_equal(got["flag"], ref["flag"])
+    assert np.array_equal(got["nres"], ref["nres"])
+    ok = (ref["flag"] == 0) | (ref["flag"] == 3)
+    assert _rel(got["rate"][ok], ref["rate"][ok], 1e-12).max() < RTOL_RATE
+    assert np.abs(got["lnl"] - ref["lnl"]).max() < 1e-9
+    assert _rel(got["subst"][ok], ref["subst"][ok], 1e-12).max() < RTOL_RATE
+    # flat columns keep the start value: rate == kappa exactly
+    assert np.array_equal(got["rate"][ref["flag"] == 1], ref["rate"][ref["flag"] == 1])
+    kat = c["kat"]
+    inf = ref["nres"] >= 3
+    assert inf.sum() == 180
+    assert np.abs(got["lnl"] - np.array(kat["ll"]))[inf].max() < 5.1e-5
+    okk = inf & ok
+    assert okk.sum() == 177
+    assert np.abs(got["rate"] - np.array(kat["rate"]))[okk].max() < 5.1e-5
+    assert np.abs(got["subst"] - np.array(kat["subst"]))[okk].max() < 5.1e-5
+    assert abs(plan.chrono_length - kat["chronogram_length"]) < 1e-12
+    plan.close()
+
+
+def test_gtr_eigen_systems(oracle):
+    engine = _engine()
+    from tapir_amd import synth
+    pi, exch = synth.locus_parameters(50, 7)
+    root, names = synth.yule_tree(8, 3)
+    pin = synth.plan_inputs(root, names)
+    off = np.arange(51) * 10
+    plan = engine.Plan(8, pin["parent"], pin["blen"], pin["leaf"], off, pi, exch, 10, [1], [[0, 1]])
+    lam, U, Ui, kappa = plan.models()
+    for l in range(50):
+        Q = U[l] @ np.diag(lam[l]) @ Ui[l]
+        olam, oU, oUi, okappa = oracle.gtr_eigen(pi[l], exch[l])
+        Qo = oU @ np.diag(olam) @ oUi
+        assert np.abs(Q - Qo).max() < 1e-13
+        assert np.abs(U[l] @ Ui[l] - np.eye(4)).max() < 1e-13
+        assert abs(kappa[l] - okappa) < 1e-14
+        assert lam[l][0] == 0.0 and np.all(U[l][:, 0] == 1.0) and np.allclose(Ui[l][0], pi[l], rtol=0, atol=1e-16)
+    plan.close()
+
+
+@pytest.mark.parametrize("ntaxa,nloci,ncols,seed", [(16, 24, 500, 11), (64, 6, 700, 12), (5, 10, 333, 13), (256, 2, 200, 14)])
+def test_synthetic_site_rates_vs_oracle(oracle, ntaxa, nloci, ncols, seed):
+    """Same seeded bytes to the HIP kernel and to the C restatement; ragged last chunks on purpose."""
+    engine = _engine()
+    from tapir_amd import synth
+    d = synth.simulate(nloci, ncols, ntaxa, seed)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"],
+                       pin["T"], [10, 30, 50, 90], [[5, 15], [25, 35]], correction=pin["correction"])
+    got = plan.site_rates(st)
+    nbad = 0
+    for l in range(nloci):
+        sl = slice(l * ncols, (l + 1) * ncols)
+        ref = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l])
+        assert np.array_equal(got["nres"][sl], ref["nres"])
+        assert np.array_equal(got["flag"][sl], ref["flag"]), (l, np.flatnonzero(got["flag"][sl] != ref["flag"]))
+        ok = (ref["flag"] == 0) | (ref["flag"] == 3)
+        rr = _rel(got["rate"][sl][ok], ref["rate"][ok], 1e-12)
+        assert rr.max() < RTOL_RATE, (l, rr.max())
+        assert np.abs(got["lnl"][sl] - ref["lnl"]).max() < 1e-8 * max(1.0, np.abs(ref["lnl"]).max())
+        nbad += int((~ok).sum())
+    assert plan.last_eval_count() > 0
+    plan.close()
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C"])
+def test_pi_tables_vs_reference_outputs(golden, case):
+    """tphip_pi_tables against outputs of the reference's own compute.py (tests/golden/make_golden.py)."""
+    engine = _engine()
+    rates = golden[case + "_rates"]
+    T = int(golden[case + "_T"])
+    times, iv = golden[case + "_times"], golden[case + "_intervals"]
+    # any 3-taxon tree will do: the PI stage never looks at it
+    parent, blen, leaf = [2, 2, 4, 4, -1], [1.0, 1.0, 1.0, 1.0, 0.0], [0, 1, -1, 2, -1]
+    plan = engine.Plan(3, parent, blen, leaf, [0, len(rates)], [[.25] * 4], [[1.0] * 6], T, times, iv,
+                       correction=1.0, threshold=0, round_decimals=-1)
+    tab = plan.pi_tables(rates)[0]
+    n_t, n_i = len(times), len(iv)
+    net, disc = tab[:T], tab[T:T + n_t]
+    integ, err = tab[T + n_t:T + n_t + n_i], tab[T + n_t + n_i:]
+    assert _rel(net[1:], golden[case + "_net"][1:]).max() < RTOL_PI
+    assert net[0] == 0.0
+    assert _rel(disc, golden[case + "_disc"], 1e-300).max() < RTOL_PI
+    assert _rel(integ, golden[case + "_sum_integral"]).max() < RTOL_PI
+    assert _rel(err, golden[case + "_sum_error"]).max() < 1e-6
+    plan.close()
+
+
+def test_phydesign_known_answers(golden_dir):
+    """test_compute.py:44-71 (PhyDesign web-site values) through the mirrored host functions."""
+    import os
+    from tapir_amd import compute
+    _engine()
+    rates = compute.parse_site_rates(os.path.join(golden_dir, "test-uniform-draw-weights.rates.json"), test=True)
+    townsend = compute.get_townsend_pi(compute.get_time(0, 174), np.array(rates))
+    assert townsend.shape == (174, 100)
+    net = np.sum(townsend, axis=1)
+    np.testing.assert_allclose(net[:6], [0.00000, 0.10778, 0.14484, 0.14616, 0.13132, 0.11089], atol=5e-6)
+    for v, e in zip([10, 20, 50], [0.03448, 0.01111, 0.02293]):
+        assert abs(net[v] - e) < 5e-6
+    expected = [0.93453, 0.10628, 0.05855, 0.12638, 1.03698, 2.08840]
+    for pair, e in zip(([0, 10], [10, 15], [15, 20], [20, 30], [20, 70], [20, 100]), expected):
+        integral, error = compute.get_integral_over_times(pair[0], pair[1], rates)
+        assert abs(sum(integral) - e) < 1e-5
+    # the two goldens the reference ships but never loads
+    r_out = np.load(os.path.join(golden_dir, "test-R-townsend-output.npy"))          # (100 sites, 101 times)
+    mine = compute.get_townsend_pi(compute.get_time(0, 101), np.array(rates))
+    assert _rel(mine[1:], r_out.T[1:]).max() < 1e-14
+    g3050 = np.load(os.path.join(golden_dir, "test-30-50-integral.npy")).ravel()
+    integral, _ = compute.get_integral_over_times(30, 50, rates)
+    assert _rel(integral, g3050).max() < 1e-14
+
+
+def test_per_site_quad_vs_reference(golden):
+    engine = _engine()
+    for case in "ABC":
+        r = golden[case + "_rates"]
+        fin = r[np.isfinite(r)]
+        for k, (a, b) in enumerate(golden[case + "_intervals"]):
+            integral, abserr = engine.quad_townsend(a, b, fin)
+            assert _rel(integral, golden[case + "_site_integral"][k], 1e-300).max() < 1e-13
+            # abserr: the deterministic floor 50*eps*resabs and the real adaptive errors agree closely; a few
+            # values are rounding noise of (resk - resg) and may differ by several percent
+            rel = _rel(abserr, golden[case + "_site_abserr"][k], 1e-300)
+            assert np.mean(rel < 1e-6) > 0.99 and rel.max() < 0.5
+
+
+def test_run_fused_matches_staged_and_oracle(chr1_918, oracle):
+    """worker() end to end for the bundled locus: rates rounded to 4 dp (Format(x,0,4)), / correction,
+    threshold-3 cull, PI tables; versus the numpy/scipy restatement fed with the oracle's rates."""
+    engine = _engine()
+    c = chr1_918
+    times, iv = [10, 20, 50], [[0, 10], [10, 15], [20, 100]]
+    plan = _plan_for(engine, c, int(c["depth"]), times, iv, correction=c["factor"], threshold=3, round_decimals=4)
+    out = plan.run_fused(c["states"])
+    ref = oracle.site_rates(c["states"], c["parent"], c["blen"], c["leaf"], c["pi"], c["exch"])
+    rates = oracle.round_dp(ref["rate"], 4) / c["factor"]
+    rates[ref["nres"] < 3] = np.nan
+    pi_net, pi_times, pi_epochs = oracle.worker_tables(rates, int(c["depth"]), times, iv)
+    T = int(c["depth"])
+    tab = out["tables"][0]
+    assert _rel(tab[1:T], pi_net[1:], 1e-300).max() < 1e-9
+    assert _rel(tab[T:T + 3], np.array([pi_times[t] for t in times])).max() < 1e-9
+    assert _rel(tab[T + 3:T + 6], np.array([pi_epochs["%d-%d" % (a, b)]["sum(integral)"] for a, b in iv])).max() < 1e-9
+    staged = plan.pi_tables(out["rate"], out["nres"])
+    assert np.array_equal(staged, out["tables"])
+    plan.close()
