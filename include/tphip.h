@@ -51,7 +51,7 @@ enum {
 enum {
     TPHIP_FLAG_OK = 0,        /* interior optimum                                                   */
     TPHIP_FLAG_FLAT = 1,      /* <= 1 resolved taxon: L independent of the rate; s stays 1 (bf:1050)  */
-    TPHIP_FLAG_SATURATED = 2, /* likelihood still increasing at s = 1e4                              */
+    TPHIP_FLAG_SATURATED = 2, /* log L flat to fp64 on the way to s -> inf (or uphill at s = 1e4): s = 1e4 */
     TPHIP_FLAG_ZERO = 3,      /* all resolved taxa share one base: optimum exactly at s = 0          */
     TPHIP_FLAG_MAXIT = 4      /* iteration limit                                                     */
 };
@@ -175,6 +175,10 @@ int tphip_townsend_pi_dense(int32_t device, const double *rates, int64_t n, cons
 int tphip_quad_townsend(int32_t device, const double *rates, int64_t n, double a, double b, int32_t integ_mode,
                         double *integral, double *abserr);
 int tphip_state_histogram(tphip_plan *plan, const uint8_t *states, int64_t *hist);
+
+/* Diagnostic (tests): log L and its first two derivatives with respect to u = log(siteRate) for every
+ * column at a caller-chosen u[ncols]; no classification, no optimiser.  Host pointers. */
+int tphip_eval_columns(tphip_plan *plan, const uint8_t *states, const double *u, double *f, double *g, double *h);
 
 #ifdef __cplusplus
 }

@@ -27,8 +27,9 @@
  * Optimiser policy (HyPhy's own derivative-free optimiser is not reproducible):
  *   maximise f(u) = log L(exp(u)) from u=0 (s=1) with a safeguarded Newton iteration that follows the
  *   uphill direction to the nearest local maximum.  Flags: 0 interior optimum, 1 flat (<=1 resolved
- *   taxon: L does not depend on s, s stays 1), 2 saturated (still uphill at s = 1e4), 3 optimum at
- *   s = 0 (all resolved taxa carry the same base), 4 iteration limit.
+ *   taxon: L does not depend on s, s stays 1), 2 saturated (log L flat to fp64 resolution on the way to
+ *   s -> infinity, or still uphill at s = 1e4: s = 1e4 is reported), 3 optimum at s = 0 (all resolved
+ *   taxa carry the same base), 4 iteration limit.
  *
  * State encoding: one byte per cell, bit mask A=1 C=2 G=4 T=8; gap/?/N = 15; IUPAC codes = unions.
  * Alignment layout: taxon-major, states[taxon*ncols + col].
@@ -47,6 +48,7 @@
 #define ORC_STEP_MAX 2.0
 #define ORC_STEP_TOL 1e-9
 #define ORC_MAXIT 100
+#define ORC_FLAT_EPS 1e-10 /* |dlogL/du| and |d2logL/du2| below this: surface flat to fp64 -> saturated */
 
 /* ------------------------------------------------------------------------------------------------
  * PI(t) and its integrals
@@ -598,6 +600,10 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
         column_loglik(m, tr, states, ncols, col, u, &f, &g, &h);
         ++*neval;
         int uphill = !(g <= 0); /* NaN (L underflowed to 0 at tiny s) counts as uphill */
+        /* Saturation: log L has reached its s -> infinity asymptote to within fp64 resolution.  Beyond this
+         * point g is a second-order-small number buried under first-order rounding noise (its sign is
+         * meaningless), so the policy value s = 1e4 is reported instead of chasing it. */
+        if (fabs(g) < ORC_FLAT_EPS && fabs(h) < ORC_FLAT_EPS) { *flag_out = 2; u = ORC_U_MAX; break; }
         if (u >= ORC_U_MAX && uphill) { *flag_out = 2; break; }
         if (u <= ORC_U_MIN && !uphill) { *flag_out = 3; break; }
         if (uphill) { lo = u; lo_open = 0; } else { hi = u; hi_open = 0; }
@@ -605,9 +611,12 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
         if (!(step <= ORC_STEP_MAX)) step = ORC_STEP_MAX;
         if (step < -ORC_STEP_MAX) step = -ORC_STEP_MAX;
         double un = u + step;
-        if (un >= hi) un = hi_open ? ORC_U_MAX : 0.5 * (lo + hi);
-        else if (un <= lo) un = lo_open ? ORC_U_MIN : 0.5 * (lo + hi);
-        step = un - u;
+        /* the bracket safeguard must not see a converged (possibly underflowing) Newton step */
+        if (fabs(step) >= ORC_STEP_TOL) {
+            if (un >= hi) un = hi_open ? ORC_U_MAX : 0.5 * (lo + hi);
+            else if (un <= lo) un = lo_open ? ORC_U_MIN : 0.5 * (lo + hi);
+            step = un - u;
+        }
         if (fabs(step) < ORC_STEP_TOL) { /* converged: take the last step with its quadratic model */
             f += g * step + 0.5 * h * step * step;
             u = un;

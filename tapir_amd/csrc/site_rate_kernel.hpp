@@ -32,6 +32,7 @@ constexpr double kUMax = 9.210340371976184;    // log(1e4)
 constexpr double kStepMax = 2.0;
 constexpr double kStepTol = 1e-9;
 constexpr int kMaxIt = 100;
+constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
 constexpr int kSiteBlock = 64;  // one wavefront per workgroup
 
 struct SiteParams {
@@ -259,7 +260,10 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
             ++evals;
             f = fe;
             const bool uphill = !(g <= 0.0);
-            if (u >= kUMax && uphill) { flg = TPHIP_FLAG_SATURATED; done = true; }
+            // Saturation: beyond this point g is second-order small under first-order rounding noise, its
+            // sign is meaningless; report the policy value s = 1e4 (same rule as the oracle).
+            if (fabs(g) < kFlatEps && fabs(h) < kFlatEps) { flg = TPHIP_FLAG_SATURATED; u = kUMax; done = true; }
+            else if (u >= kUMax && uphill) { flg = TPHIP_FLAG_SATURATED; done = true; }
             else if (u <= kUMin && !uphill) { flg = TPHIP_FLAG_ZERO; done = true; }
             else {
                 if (uphill) { lo = u; lo_open = false; } else { hi = u; hi_open = false; }
@@ -267,9 +271,12 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
                 if (!(step <= kStepMax)) step = kStepMax;
                 if (step < -kStepMax) step = -kStepMax;
                 double un = u + step;
-                if (un >= hi) un = hi_open ? kUMax : 0.5 * (lo + hi);
-                else if (un <= lo) un = lo_open ? kUMin : 0.5 * (lo + hi);
-                step = un - u;
+                // the bracket safeguard must not see a converged (possibly underflowing) Newton step
+                if (fabs(step) >= kStepTol) {
+                    if (un >= hi) un = hi_open ? kUMax : 0.5 * (lo + hi);
+                    else if (un <= lo) un = lo_open ? kUMin : 0.5 * (lo + hi);
+                    step = un - u;
+                }
                 if (fabs(step) < kStepTol) {
                     f = fma(step, fma(0.5 * h, step, g), f);  // f + g*step + h*step^2/2
                     flg = TPHIP_FLAG_OK;
@@ -292,6 +299,43 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (lane == 0 && P.eval_counter) atomicAdd(P.eval_counter, (unsigned long long)tot);
+}
+
+// Diagnostic: evaluate f = log L, g = df/du, h = d2f/du2 at a caller-chosen u for EVERY column (no
+// classification, no optimiser).  Tests use it to check the derivative propagation by finite differences.
+struct EvalParams {
+    SiteParams S;
+    const double* u;
+    double* f;
+    double* g;
+    double* h;
+};
+
+__global__ __launch_bounds__(kSiteBlock) void eval_columns_kernel(EvalParams E) {
+    extern __shared__ double lds[];
+    double* wtab = lds;
+    double* stack = lds + 64;
+    const SiteParams& P = E.S;
+    const int chunk = blockIdx.x;
+    const int locus = P.chunk_locus[chunk];
+    const int cidx = P.chunk_index[chunk];
+    const LocusModel* __restrict__ M = P.models + locus;
+    const int lane = threadIdx.x;
+    {
+        int mask = lane >> 2, k = lane & 3;
+        double w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w += ((mask >> j) & 1) ? M->Ui[k * 4 + j] : 0.0;
+        wtab[lane] = w;
+    }
+    __syncthreads();
+    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+    const int64_t want = lo + (int64_t)cidx * kSiteBlock + lane;
+    const bool active = want < hi;
+    const int64_t col = active ? want : lo;
+    double f, g, h;
+    evaluate_column(P, M, wtab, stack, col, exp(E.u[col]), f, g, h);
+    if (active) { E.f[col] = f; E.g[col] = g; E.h[col] = h; }
 }
 
 }  // namespace tphip

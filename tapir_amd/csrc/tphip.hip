@@ -525,6 +525,36 @@ int tphip_quad_townsend(int32_t device, const double* rates, int64_t n, double a
     return TPHIP_OK;
 }
 
+int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, double* f, double* g, double* h) {
+    if (!p || !states || !u || !f || !g || !h) return fail(TPHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    Scratch S;
+    const size_t n = (size_t)p->ncols;
+    uint8_t* d_s = S.get<uint8_t>(n * (size_t)p->ntaxa);
+    double* d_u = S.get<double>(n);
+    double* d_f = S.get<double>(n);
+    double* d_g = S.get<double>(n);
+    double* d_h = S.get<double>(n);
+    if (!d_s || !d_u || !d_f || !d_g || !d_h) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_s, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_u, u, sizeof(double) * n, hipMemcpyHostToDevice));
+    EvalParams E;
+    E.S.states = d_s; E.S.ncols_total = p->ncols; E.S.models = p->d_models.p; E.S.ops = p->d_ops.p;
+    E.S.nops = (int32_t)p->prog.ops.size(); E.S.stack_depth = p->prog.stack_depth; E.S.chrono_length = p->prog.chrono_length;
+    E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
+    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
+    E.S.flag = nullptr; E.S.eval_counter = nullptr;
+    E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
+    const size_t lds = (64 + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    if (p->n_site_chunks > 0) eval_columns_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds>>>(E);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(f, d_f, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(g, d_g, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h, d_h, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
+}
+
 int tphip_state_histogram(tphip_plan* p, const uint8_t* states, int64_t* hist) {
     if (!p || !states || !hist) return fail(TPHIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(p->device));

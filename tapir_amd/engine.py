@@ -59,6 +59,7 @@ SYMBOLS = [
     ("tphip_townsend_pi_dense", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp]),
     ("tphip_quad_townsend", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp]),
     ("tphip_state_histogram", ctypes.c_int, [_vp, _vp, _vp]),
+    ("tphip_eval_columns", ctypes.c_int, [_vp] * 6),
 ]
 
 _lib = None
@@ -190,6 +191,16 @@ class Plan:
         hist = np.empty((self.nloci, 16), np.int64)
         _check(self._lib.tphip_state_histogram(self._h, states.ctypes.data, hist.ctypes.data))
         return hist
+
+    def eval_columns(self, states, u):
+        """Diagnostic: (f, g, h) = log L and its u-derivatives for every column at u[ncols]."""
+        states = _np(states, np.uint8)
+        u = _np(u, np.float64)
+        assert u.shape == (self.ncols,)
+        f, g, h = np.empty(self.ncols), np.empty(self.ncols), np.empty(self.ncols)
+        _check(self._lib.tphip_eval_columns(self._h, states.ctypes.data, u.ctypes.data, f.ctypes.data, g.ctypes.data,
+                                            h.ctypes.data))
+        return f, g, h
 
     def models(self):
         L = self.nloci
