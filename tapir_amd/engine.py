@@ -43,6 +43,7 @@ SYMBOLS = [
     ("tphip_plan_workspace_bytes", ctypes.c_size_t, [_vp]),
     ("tphip_plan_chrono_length", _f64, [_vp]),
     ("tphip_plan_stack_depth", _i32, [_vp]),
+    ("tphip_plan_op_counts", ctypes.c_int, [_vp, _vp]),
     ("tphip_plan_get_models", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("tphip_site_rates_dev", ctypes.c_int, [_vp] * 8 + [ctypes.c_size_t, _vp]),
     ("tphip_pi_tables_dev", ctypes.c_int, [_vp] * 5 + [ctypes.c_size_t, _vp]),
@@ -141,6 +142,9 @@ class Plan:
         self.workspace_bytes = lib.tphip_plan_workspace_bytes(self._h)
         self.chrono_length = lib.tphip_plan_chrono_length(self._h)
         self.stack_depth = lib.tphip_plan_stack_depth(self._h)
+        oc = np.zeros(5, np.int32)
+        _check(lib.tphip_plan_op_counts(self._h, oc.ctypes.data))
+        self.op_counts = dict(zip(("tip_set", "tip_mul", "branch", "push", "pop_mul"), oc.tolist()))
 
     def close(self):
         if self._h:
