@@ -153,8 +153,10 @@ int tphip_quad_townsend_dev(int32_t device, const double *d_rates, int64_t n, do
                             int32_t integ_mode, double *d_integral, double *d_abserr, void *stream);
 
 /* HarvestFrequencies(Freqs, filter, 1, 1, 1) (bf:968): per-locus counts of each of the 16 state masks;
- * d_hist is [nloci][16] int64 (pi follows on the host: each mask adds 1/popcount to its bases). */
-int tphip_state_histogram_dev(tphip_plan *plan, const uint8_t *d_states, int64_t *d_hist, void *stream);
+ * d_hist is [nloci][16] int64 (pi follows on the host: each mask adds 1/popcount to its bases).
+ * d_locus_offsets is a DEVICE array [nloci+1].  HBM-bound byte kernel: ntaxa bytes read per column. */
+int tphip_state_histogram_dev(int32_t device, const uint8_t *d_states, int64_t ncols_total, int32_t ntaxa,
+                              const int64_t *d_locus_offsets, int64_t nloci, int64_t *d_hist, void *stream);
 
 /* Profiling hooks for bench.py: when enabled the library brackets its dominant kernel (site rates) with
  * HIP events on the caller's stream and accumulates the elapsed time. */
@@ -176,7 +178,8 @@ int tphip_townsend_pi_dense(int32_t device, const double *rates, int64_t n, cons
                             double *out);
 int tphip_quad_townsend(int32_t device, const double *rates, int64_t n, double a, double b, int32_t integ_mode,
                         double *integral, double *abserr);
-int tphip_state_histogram(tphip_plan *plan, const uint8_t *states, int64_t *hist);
+int tphip_state_histogram(int32_t device, const uint8_t *states, int64_t ncols_total, int32_t ntaxa,
+                          const int64_t *locus_offsets, int64_t nloci, int64_t *hist);
 
 /* Diagnostic (tests): log L and its first two derivatives with respect to u = log(siteRate) for every
  * column at a caller-chosen u[ncols]; no classification, no optimiser.  Host pointers. */

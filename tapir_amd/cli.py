@@ -1,0 +1,170 @@
+"""tapir_compute.py, GPU edition: the reference's command line (bin/tapir_compute.py:18-53, 125-177) with the
+per-locus HyPhy loop replaced by one batched call into the HIP engine.
+
+Same positionals, same required/optional flags and defaults, same output directory contents
+(Tree_<factor>_<depth>.newick, <alignment>.rates JSON per locus, phylogenetic-informativeness.sqlite).
+`--hyphy`, `--template` and `--multiprocessing` are accepted for compatibility and ignored (there is no
+subprocess and no process pool).  New, opt-in flags only: --device, --exchangeabilities / --subs-model,
+--integral-mode, --full-precision-rates.
+
+Stage 1 of the HyPhy script (203-model fit + model averaging of the GTR exchangeabilities,
+models_and_rates.bf:405-897) is not part of this engine yet: the exchangeabilities are an
+input, defaulting to all ones with empirical base frequencies.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import base, compute, db, newick, pipeline
+
+
+def get_args(argv=None):
+    """Get CLI arguments and options (mirrors bin/tapir_compute.py:18-53)."""
+    parser = argparse.ArgumentParser(description="""tapir:  compute the
+            phylogenetic informativeness of DNA loci""")
+    parser.add_argument('alignments', help="The folder of alignments", action=base.FullPaths, type=base.is_dir)
+    parser.add_argument('tree', help="The input tree", action=base.FullPaths)
+    required = parser.add_argument_group("required arguments")
+    required.add_argument('--times', help="""Comma-separated list of start
+        times of interest (MYA)""", type=base.get_list_from_ints, required=True)
+    required.add_argument('--intervals', help="""Comma-separated list of
+        interval ranges of interest (i,e. in MYA)""", type=base.get_list_from_ranges, required=True)
+    parser.add_argument('--tree-format', help="The format of the tree", dest='tree_format',
+                        choices=['nexus', 'newick'], default='newick')
+    parser.add_argument('--output', help="The path to the output directory", default=os.getcwd(),
+                        action=base.FullPaths, type=base.is_dir)
+    parser.add_argument('--hyphy', help="Ignored (kept for compatibility): there is no hyphy subprocess",
+                        default="hyphy2")
+    parser.add_argument('--template', help="Ignored (kept for compatibility)", default=None)
+    parser.add_argument('--threshold', help="""Minimum number of taxa without
+        a gap for a site to be considered informative""", default=3, type=int)
+    parser.add_argument('--multiprocessing', help="Ignored (kept for compatibility): loci are batched on the GPU",
+                        default=False, action='store_true')
+    parser.add_argument('--site-rates', default=False, action='store_true',
+                        help="Use previously calculated site rates")
+    parser.add_argument('--subset-pi-map-file', help="""Calculate PI for a
+        subset of sites. If specified, this should be a tab-delimited file
+        with the alignment file name in the 1st column, the start of the
+        interval (0-offset) in the 2nd column, and the end of the interval in
+        the 3rd column.""")
+    new = parser.add_argument_group("MI355X engine options (not in the reference)")
+    new.add_argument('--device', type=int, default=0, help="HIP device ordinal")
+    new.add_argument('--exchangeabilities', type=_six_floats, default=None,
+                     help="AC,AG,AT,CG,CT,GT used for every locus (default 1,1,1,1,1,1)")
+    new.add_argument('--subs-model', default=None,
+                     help="tab-delimited file: alignment file name, AC, AG, AT, CG, CT, GT [, A, C, G, T frequencies]")
+    new.add_argument('--integral-mode', choices=['quadpack', 'closed'], default='quadpack',
+                     help="quadpack = emulate scipy.integrate.quad incl. its error column; closed = analytic")
+    new.add_argument('--full-precision-rates', action='store_true',
+                     help="do not round site rates to 4 decimals before PI (the reference rounds through its JSON file)")
+    return parser.parse_args(argv)
+
+
+def _six_floats(string):
+    try:
+        v = [float(x) for x in string.split(',')]
+        assert len(v) == 6
+    except Exception as e:
+        raise argparse.ArgumentTypeError("Cannot convert exchangeabilities to six numbers: {0}".format(e))
+    return v
+
+
+def welcome_message():
+    return '''
+    ***************************************************
+    *                                                 *
+    * tapir: high-throughput estimates of             *
+    * phylogenetic informativeness                    *
+    *                                                 *
+    * MI355X engine (tapir_amd): site-rate ML and PI  *
+    * in one HIP pipeline.  Method credits:           *
+    *                                                 *
+    *   - J.P. Townsend, 2007. Profiling              *
+    *     phylogenetic informativeness. Systematic    *
+    *     Biology, 56(2), 222-231.                    *
+    *                                                 *
+    *   - Pond, S.L.K., Frost, S.D.W., and S.V. Muse, *
+    *     2005. Hyphy: hypothesis testing using       *
+    *     phylogenies. Bioinformatics, 21(5), 676-9.  *
+    *                                                 *
+    *   - B.C. Faircloth, J. Chang, M.E. Alfaro, 2012.*
+    *     TAPIR (the program this engine drops into). *
+    *                                                 *
+    ***************************************************\n\n'''
+
+
+def read_subs_model(path, alignments):
+    table = {}
+    with open(path) as fh:
+        for line in fh:
+            parts = line.rstrip("\n").split("\t")
+            if len(parts) >= 7 and not line.startswith("#"):
+                table[parts[0]] = [float(x) for x in parts[1:]]
+    exch, pi = [], []
+    for a in alignments:
+        b = os.path.basename(a)
+        if b not in table:
+            raise IOError("no substitution model for {0} in {1}".format(b, path))
+        exch.append(table[b][:6])
+        pi.append(table[b][6:10] if len(table[b]) >= 10 else None)
+    pis = None if any(p is None for p in pi) else np.array(pi)
+    return np.array(exch), pis
+
+
+def main(argv=None, engine_mod=None):
+    """Main loop (mirrors bin/tapir_compute.py:125-177)."""
+    args = get_args(argv)
+    print(welcome_message())
+    args.output = base.create_unique_dir(args.output)
+    # correct branch lengths
+    tree_depth, correction, tree = compute.correct_branch_lengths(args.tree, args.tree_format, d=args.output)
+    # generate a vector of times given start and stops
+    T = int(tree_depth)
+    subset_pi = dict()
+    if args.subset_pi_map_file:
+        subset_pi = dict(base.parse_subset_map_file(args.subset_pi_map_file))
+    root = newick.read_tree(tree, 'newick')
+    leaf_names = [n.name for n in newick.leaves(root)]
+    parent, blen, leaf = newick.to_arrays(root, leaf_names)
+    integ_mode = 0 if args.integral_mode == 'quadpack' else 1
+    if not args.site_rates:
+        print("\nEstimating site rates and PI for files:")
+        alignments = base.get_files(args.alignments, '*.nex,*.nexus')
+        exch, pi = np.ones(6), None
+        if args.exchangeabilities is not None:
+            exch = np.array(args.exchangeabilities)
+        if args.subs_model:
+            exch, pi = read_subs_model(args.subs_model, alignments)
+        elif args.exchangeabilities is None:
+            sys.stderr.write("tapir_amd: no --exchangeabilities/--subs-model given: using AC=AG=AT=CG=CT=GT=1 with "
+                             "empirical base frequencies (HyPhy's stage-1 model averaging is not part of this engine)\n")
+        pis, _ = pipeline.run_alignments(alignments, leaf_names, parent, blen, leaf, T, args.times, args.intervals,
+                                         correction, args.threshold, exch, pi=pi, subsets=subset_pi,
+                                         output_dir=args.output, device=args.device, integ_mode=integ_mode,
+                                         round_decimals=-1 if args.full_precision_rates else 4,
+                                         engine_mod=engine_mod, progress=pipeline.dot_progress)
+    else:
+        print("Estimating PI for files (--site-rate option):")
+        rate_files = base.get_files(args.alignments, '*.rates')
+        pis = pipeline.run_rate_files(rate_files, leaf_names, parent, blen, leaf, T, args.times, args.intervals,
+                                      correction, subsets=subset_pi, device=args.device, integ_mode=integ_mode,
+                                      engine_mod=engine_mod, progress=pipeline.dot_progress)
+    # store results somewhere
+    db_name = os.path.join(args.output, 'phylogenetic-informativeness.sqlite')
+    sys.stdout.write("\nStoring results in {0}...".format(db_name))
+    sys.stdout.flush()
+    conn, c = db.create_probe_db(db_name)
+    db.insert_pi_data(conn, c, pis)
+    conn.commit()
+    sys.stdout.write("DONE")
+    sys.stdout.flush()
+    print("\n")
+    c.close()
+    conn.close()
+    return args.output
+
+
+if __name__ == '__main__':
+    main()

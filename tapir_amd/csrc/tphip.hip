@@ -415,11 +415,13 @@ int tphip_quad_townsend_dev(int32_t device, const double* d_rates, int64_t n, do
     return TPHIP_OK;
 }
 
-int tphip_state_histogram_dev(tphip_plan* p, const uint8_t* d_states, int64_t* d_hist, void* stream) {
-    if (!p || !d_states || !d_hist) return fail(TPHIP_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(p->device));
-    state_histogram_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, (hipStream_t)stream>>>(
-        d_states, p->ncols, p->ntaxa, p->d_offsets.p, (unsigned long long*)d_hist);
+int tphip_state_histogram_dev(int32_t device, const uint8_t* d_states, int64_t ncols_total, int32_t ntaxa,
+                              const int64_t* d_locus_offsets, int64_t nloci, int64_t* d_hist, void* stream) {
+    if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (!d_states || !d_locus_offsets || !d_hist || nloci < 1 || ntaxa < 1) return fail(TPHIP_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    state_histogram_kernel<<<dim3((unsigned)nloci), dim3(256), 0, (hipStream_t)stream>>>(
+        d_states, ncols_total, ntaxa, d_locus_offsets, (unsigned long long*)d_hist);
     HIP_TRY(hipGetLastError());
     return TPHIP_OK;
 }
@@ -563,21 +565,23 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     return TPHIP_OK;
 }
 
-int tphip_state_histogram(tphip_plan* p, const uint8_t* states, int64_t* hist) {
-    if (!p || !states || !hist) return fail(TPHIP_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(p->device));
-    uint8_t* d_s = nullptr; int64_t* d_h = nullptr;
-    const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
-    HIP_TRY(hipMalloc((void**)&d_s, nb + 1));
-    if (hipMalloc((void**)&d_h, sizeof(int64_t) * 16 * (size_t)p->nloci) != hipSuccess) { (void)hipFree(d_s); return fail(TPHIP_ERR_HIP, "hipMalloc failed"); }
-    int rc = TPHIP_OK;
-    if (hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice) != hipSuccess) rc = fail(TPHIP_ERR_HIP, "H2D failed");
-    if (!rc) rc = tphip_state_histogram_dev(p, d_s, d_h, nullptr);
-    if (!rc && hipMemcpy(hist, d_h, sizeof(int64_t) * 16 * (size_t)p->nloci, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(TPHIP_ERR_HIP, "D2H failed");
-    (void)hipFree(d_s);
-    (void)hipFree(d_h);
-    return rc;
+int tphip_state_histogram(int32_t device, const uint8_t* states, int64_t ncols_total, int32_t ntaxa,
+                          const int64_t* locus_offsets, int64_t nloci, int64_t* hist) {
+    if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (!states || !locus_offsets || !hist || nloci < 1 || ntaxa < 1 || ncols_total < 0) return fail(TPHIP_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    Scratch S;
+    const size_t nb = (size_t)ncols_total * (size_t)ntaxa;
+    uint8_t* d_s = S.get<uint8_t>(nb);
+    int64_t* d_o = S.get<int64_t>((size_t)nloci + 1);
+    int64_t* d_h = S.get<int64_t>(16 * (size_t)nloci);
+    if (!d_s || !d_o || !d_h) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_o, locus_offsets, sizeof(int64_t) * ((size_t)nloci + 1), hipMemcpyHostToDevice));
+    int rc = tphip_state_histogram_dev(device, d_s, ncols_total, ntaxa, d_o, nloci, d_h, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(hist, d_h, sizeof(int64_t) * 16 * (size_t)nloci, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
 }
 
 }  // extern "C"

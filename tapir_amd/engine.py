@@ -50,7 +50,7 @@ SYMBOLS = [
     ("tphip_run_dev", ctypes.c_int, [_vp] * 9 + [ctypes.c_size_t, _vp]),
     ("tphip_townsend_pi_dense_dev", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     ("tphip_quad_townsend_dev", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp, _vp]),
-    ("tphip_state_histogram_dev", ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    ("tphip_state_histogram_dev", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     ("tphip_profile_enable", ctypes.c_int, [_vp, _i32]),
     ("tphip_profile_read", ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_f64), ctypes.POINTER(_i64), _i32]),
     ("tphip_last_eval_count", ctypes.c_int, [_vp, ctypes.POINTER(_i64)]),
@@ -59,7 +59,7 @@ SYMBOLS = [
     ("tphip_run_fused", ctypes.c_int, [_vp] * 8),
     ("tphip_townsend_pi_dense", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp]),
     ("tphip_quad_townsend", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp]),
-    ("tphip_state_histogram", ctypes.c_int, [_vp, _vp, _vp]),
+    ("tphip_state_histogram", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     ("tphip_eval_columns", ctypes.c_int, [_vp] * 6),
 ]
 
@@ -190,12 +190,6 @@ class Plan:
                                          out["tables"].ctypes.data))
         return out
 
-    def state_histogram(self, states):
-        states = _np(states, np.uint8)
-        hist = np.empty((self.nloci, 16), np.int64)
-        _check(self._lib.tphip_state_histogram(self._h, states.ctypes.data, hist.ctypes.data))
-        return hist
-
     def eval_columns(self, states, u):
         """Diagnostic: (f, g, h) = log L and its u-derivatives for every column at u[ncols]."""
         states = _np(states, np.uint8)
@@ -227,9 +221,6 @@ class Plan:
         _check(self._lib.tphip_pi_tables_dev(self._h, _ptr(d_rates), _ptr(d_nres), _ptr(d_tables), _ptr(d_ws),
                                              d_ws.numel() * d_ws.element_size(), stream))
 
-    def state_histogram_dev(self, d_states, d_hist, stream=0):
-        _check(self._lib.tphip_state_histogram_dev(self._h, _ptr(d_states), _ptr(d_hist), stream))
-
     def profile_enable(self, on=True):
         _check(self._lib.tphip_profile_enable(self._h, 1 if on else 0))
 
@@ -242,6 +233,17 @@ class Plan:
         n = _i64()
         _check(self._lib.tphip_last_eval_count(self._h, ctypes.byref(n)))
         return n.value
+
+
+def state_histogram(states, locus_offsets, device=0):
+    """Per-locus histogram [L, 16] of the state masks (HarvestFrequencies, bf:968), counted on the GPU."""
+    states = _np(states, np.uint8)
+    off = _np(locus_offsets, np.int64)
+    ntaxa, ncols = states.shape
+    hist = np.empty((len(off) - 1, 16), np.int64)
+    _check(load().tphip_state_histogram(device, states.ctypes.data, ncols, ntaxa, off.ctypes.data, len(off) - 1,
+                                        hist.ctypes.data))
+    return hist
 
 
 def townsend_pi_dense(times, rates, device=0):

@@ -1,0 +1,168 @@
+"""All loci at once: the batch replacement of `pis = Pool.map(worker, params)` (bin/tapir_compute.py:84-164).
+
+worker() in the reference handles ONE locus: shell out to HyPhy, read its JSON back, cull, compute PI and
+its sums and integrals.  Here every alignment column of every locus is flattened into one column-parallel
+batch (taxon-major state masks + CSR locus offsets), one call into the HIP engine produces per-site
+(rate, subst, lnL) and the per-locus PI tables, and the host only writes the reference's own artefacts:
+`<alignment>.rates` JSON files (schema of models_and_rates.bf:1018-1104 plus `corrected_rates`,
+tapir/compute.py:40-43) and worker()-shaped result tuples for tapir_amd.db.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+from . import nexus
+
+
+class PipelineError(Exception):
+    pass
+
+
+def load_alignments(paths, leaf_names):
+    """Read NEXUS alignments and flatten them: returns (states uint8 [ntaxa, ncols_total], offsets int64[L+1]).
+    Rows follow `leaf_names` (the tree's leaves); an alignment must hold exactly those taxa, as HyPhy
+    requires of (siteFilter, siteTree)."""
+    blocks, offsets = [], [0]
+    want = set(leaf_names)
+    for p in paths:
+        names, st = nexus.read_states(p)
+        have = set(names)
+        if have != want:
+            missing, extra = sorted(want - have), sorted(have - want)
+            raise PipelineError("hyphy error: taxa of {0} do not match the tree (missing {1}, not in tree {2})".format(
+                os.path.basename(p), missing, extra))
+        order = [names.index(n) for n in leaf_names]
+        blocks.append(st[order])
+        offsets.append(offsets[-1] + st.shape[1])
+    states = np.concatenate(blocks, axis=1) if blocks else np.zeros((len(leaf_names), 0), np.uint8)
+    return np.ascontiguousarray(states), np.asarray(offsets, dtype=np.int64)
+
+
+def format_rates_json(freqs, exch, site, subst, rate, ll, corrected):
+    """The per-locus site-rate document: HyPhy's writer (bf:1018-1031, 1040, 1091-1101) then tapir's
+    parse_site_rates rewrite (tapir/compute.py:40-43).  subst/rate/ll carry 4 decimals (Format(x,0,4))."""
+    r4 = lambda v: float("%.4f" % v)  # noqa: E731
+    return {"sites": {
+        "freqs": {"A": float(freqs[0]), "C": float(freqs[1]), "G": float(freqs[2]), "T": float(freqs[3])},
+        "subs_matrix": {"AC": float(exch[0]), "AG": float(exch[1]), "AT": float(exch[2]), "CG": float(exch[3]),
+                        "CT": float(exch[4]), "GT": float(exch[5])},
+        "rates": [{"site": int(s), "subst": r4(a), "rate": r4(b), "ll": r4(c)} for s, a, b, c in zip(site, subst, rate, ll)],
+        "corrected_rates": [{"site": int(s), "rate": float(v)} for s, v in zip(site, corrected)],
+    }}
+
+
+def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
+                   exch, pi=None, subsets=None, output_dir=None, device=0, integ_mode=0, round_decimals=4,
+                   engine_mod=None, progress=None):
+    """Site rates + PI for a list of NEXUS alignments.  Returns a list of worker()-shaped tuples
+    (alignment, rates, mean_rate, None, pi_net, pi_times, pi_epochs) in the order of `alignments`.
+
+    exch: [6] or [L,6] exchangeabilities AC,AG,AT,CG,CT,GT; pi: None (empirical, HarvestFrequencies) or [L,4]."""
+    eng = engine_mod
+    if eng is None:
+        from . import engine as eng
+    subsets = subsets or {}
+    states, offsets = load_alignments(alignments, leaf_names)
+    L = len(alignments)
+    if pi is None:
+        hist = eng.state_histogram(states, offsets, device=device)
+        pi = nexus.base_frequencies_from_histogram(hist)
+    pi = np.asarray(pi, dtype=np.float64).reshape(L, 4)
+    exch = np.asarray(exch, dtype=np.float64)
+    if exch.ndim == 1:
+        exch = np.tile(exch, (L, 1))
+    plan = eng.Plan(len(leaf_names), parent, blen, leaf, offsets, pi, exch, T, times, intervals,
+                    correction=correction, threshold=threshold, round_decimals=round_decimals,
+                    integ_mode=integ_mode, device=device)
+    try:
+        need_subset = any(os.path.basename(a) in subsets for a in alignments)
+        if need_subset:
+            out = plan.site_rates(states)
+        else:
+            out = plan.run_fused(states)
+    finally:
+        plan.close()
+    # what tapir would have after parse_site_rates + cull (bin/tapir_compute.py:100-102)
+    rate4 = np.round(out["rate"] * 10.0 ** round_decimals) / 10.0 ** round_decimals if round_decimals >= 0 else out["rate"]
+    corrected = rate4 / correction
+    culled = np.where(out["nres"] >= threshold, corrected, np.nan)
+    per_locus = []
+    for l, a in enumerate(alignments):
+        sl = slice(offsets[l], offsets[l + 1])
+        r = culled[sl]
+        base = os.path.basename(a)
+        if base in subsets:
+            r = r[subsets[base][0]:subsets[base][1]]
+        per_locus.append(r)
+        if output_dir is not None:
+            n = offsets[l + 1] - offsets[l]
+            doc = format_rates_json(pi[l], exch[l], np.arange(1, n + 1), out["subst"][sl], rate4[sl], out["lnl"][sl],
+                                    corrected[sl])
+            with open(os.path.join(output_dir, base + ".rates"), "w") as fh:
+                json.dump(doc, fh, indent=4)
+        if progress:
+            progress()
+    if need_subset:
+        tables = _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode)
+    else:
+        tables = out["tables"]
+    return _tuples(alignments, per_locus, tables, T, times, intervals), out
+
+
+def run_rate_files(rate_files, leaf_names, parent, blen, leaf, T, times, intervals, correction, subsets=None,
+                   device=0, integ_mode=0, engine_mod=None, progress=None):
+    """The --site-rates path (bin/tapir_compute.py:103-104, 153-158): re-read "rate" from each JSON, divide by
+    the correction (again: the reference does not read `corrected_rates`), rewrite the file, NO culling."""
+    from . import compute
+    eng = engine_mod
+    if eng is None:
+        from . import engine as eng
+    subsets = subsets or {}
+    per_locus = []
+    for f in rate_files:
+        r = compute.parse_site_rates(f, correction=correction)
+        base = os.path.basename(f)
+        if base in subsets:
+            r = r[subsets[base][0]:subsets[base][1]]
+        per_locus.append(r)
+        if progress:
+            progress()
+    tables = _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode)
+    return _tuples(rate_files, per_locus, tables, T, times, intervals)
+
+
+def _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode):
+    """PI tables for already-final rates (NaN = culled): tphip_pi_tables with no rounding/correction/cull."""
+    offsets = np.concatenate([[0], np.cumsum([len(r) for r in per_locus])]).astype(np.int64)
+    rates = np.concatenate(per_locus) if per_locus else np.zeros(0)
+    L = len(per_locus)
+    plan = eng.Plan(len(leaf_names), parent, blen, leaf, offsets, np.full((L, 4), 0.25), np.ones((L, 6)), T, times,
+                    intervals, correction=1.0, threshold=0, round_decimals=-1, integ_mode=integ_mode, device=device)
+    try:
+        return plan.pi_tables(rates, None)
+    finally:
+        plan.close()
+
+
+def _tuples(names, per_locus, tables, T, times, intervals):
+    n_t, n_i = len(times), len(intervals)
+    out = []
+    for l, name in enumerate(names):
+        row = tables[l]
+        rates = per_locus[l]
+        fin = rates[~np.isnan(rates)]
+        mean_rate = float(fin.mean()) if fin.size else float("nan")  # bin/tapir_compute.py:110 (never stored)
+        pi_net = row[:T].copy()
+        pi_times = dict(zip(times, row[T:T + n_t]))
+        pi_epochs = {}
+        for k, (a, b) in enumerate(intervals):
+            pi_epochs["{0}-{1}".format(a, b)] = {"sum(integral)": row[T + n_t + k], "sum(error)": row[T + n_t + n_i + k]}
+        out.append((name, rates, mean_rate, None, pi_net, pi_times, pi_epochs))
+    return out
+
+
+def dot_progress():
+    sys.stdout.write(".")
+    sys.stdout.flush()

@@ -207,3 +207,66 @@ def test_run_fused_matches_staged_and_oracle(chr1_918, oracle):
     staged = plan.pi_tables(out["rate"], out["nres"])
     assert np.array_equal(staged, out["tables"])
     plan.close()
+
+
+def test_cli_end_to_end_on_gpu(golden_dir, tmp_path, oracle):
+    """BASELINE config C1 through the real engine: tapir_compute.py on the bundled locus + tree; checks the
+    output directory contents, the JSON schema and values, and the byte-identical sqlite schema."""
+    _engine()
+    from test_host_logic import _run_cli, check_cli_outputs
+    outdir, _ = _run_cli(golden_dir, tmp_path)
+    check_cli_outputs(outdir, oracle, golden_dir)
+
+
+def test_state_histogram_and_dense_pi_edge_cases():
+    engine = _engine()
+    from tapir_amd import synth
+    d = synth.simulate(5, 300, 7, 21)
+    st = d["states"].numpy()
+    off = np.array([0, 300, 300, 900, 1200, 1500])  # an empty locus in the middle
+    hist = engine.state_histogram(st, off)
+    for l in range(5):
+        blk = st[:, off[l]:off[l + 1]].ravel()
+        assert np.array_equal(hist[l], np.bincount(blk, minlength=16)[:16])
+    # NaN and zero rates, scalar time, time 0
+    out = engine.townsend_pi_dense([0.0, 1.0, 2.5], [0.0, np.nan, 0.3])
+    assert out[0][0] == 0.0 and np.isnan(out[1][1]) and np.isnan(out[0][1])
+    assert abs(out[2][2] - 16 * 0.09 * 2.5 * np.exp(-4 * 0.3 * 2.5)) < 1e-15
+    # empty inputs
+    assert engine.townsend_pi_dense([], [0.1]).shape == (0, 1)
+    i, e = engine.quad_townsend(0, 10, [])
+    assert i.size == 0 and e.size == 0
+
+
+def test_plan_rejects_bad_arguments(chr1_918):
+    engine = _engine()
+    c = chr1_918
+    args = (5, c["parent"], c["blen"], c["leaf"], [0, 226], [c["pi"]], [c["exch"]], 174)
+    with pytest.raises(engine.TphipError, match="outside 0..T-1"):
+        engine.Plan(*args, [174], [[0, 10]])
+    with pytest.raises(engine.TphipError, match="Start time"):
+        engine.Plan(*args, [10], [[10, 10]])
+    with pytest.raises(engine.TphipError, match="post-order"):
+        engine.Plan(5, c["parent"][::-1].copy(), c["blen"], c["leaf"], [0, 226], [c["pi"]], [c["exch"]], 174, [1], [[0, 1]])
+    with pytest.raises(engine.TphipError, match="frequencies"):
+        engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, 226], [[0.5, 0.5, 0.0, 0.0]], [c["exch"]], 174, [1], [[0, 1]])
+
+
+def test_all_gap_and_ragged_loci(oracle):
+    """Edge cases the domain has: empty locus, all-gap columns, single-column locus, a 2-taxon tree."""
+    engine = _engine()
+    parent, blen, leaf = [2, 2, -1], [0.3, 0.7, 0.0], [0, 1, -1]
+    st = np.array([[1, 15, 2, 4, 8, 1, 15], [1, 15, 15, 4, 1, 2, 8]], dtype=np.uint8)
+    off = [0, 0, 1, 7]
+    pi = np.array([[.1, .2, .3, .4]] * 3)
+    ex = np.array([[1, 2, .5, .7, 3, 1.]] * 3)
+    plan = engine.Plan(2, parent, blen, leaf, off, pi, ex, 5, [1], [[0, 2]], threshold=2, round_decimals=-1)
+    got = plan.run_fused(st)
+    ref = oracle.site_rates(st, np.array(parent, np.int32), np.array(blen), np.array(leaf, np.int32), pi[0], ex[0])
+    assert np.array_equal(got["flag"], ref["flag"]) and np.array_equal(got["nres"], ref["nres"])
+    ok = (ref["flag"] == 0) | (ref["flag"] == 3)
+    assert np.allclose(got["rate"][ok], ref["rate"][ok], rtol=1e-6, atol=0)
+    assert np.allclose(got["lnl"], ref["lnl"], rtol=0, atol=1e-12)
+    assert got["lnl"][1] == 0.0 and got["flag"][1] == 1          # all-gap column: L = 1
+    assert np.all(got["tables"][0] == 0.0)                       # empty locus -> zero row
+    plan.close()

@@ -1,0 +1,377 @@
+"""Host logic above the C ABI, on CPU (`-m "not gpu"`): argparse helpers (the reference's test_base.py),
+tree / NEXUS readers, tree correction (test_compute.py:76-91), JSON and sqlite writers, the CLI end to end
+with the oracle-backed test engine, the C ABI's symbol table, and the gloo all-gather of PI tables."""
+import argparse
+import ctypes
+import json
+import os
+import re
+import shutil
+import sqlite3
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- tapir/tests/test_base.py, restated -----------------------------------------------------------
+def test_is_dir(tmp_path):
+    from tapir_amd.base import is_dir
+    assert is_dir(str(tmp_path))
+    with pytest.raises(argparse.ArgumentTypeError):
+        is_dir(str(tmp_path / "nope"))
+
+
+def test_get_output_type():
+    from tapir_amd.base import get_output_type
+    assert get_output_type('test.jpg') == 'jpg'
+    with pytest.raises(AssertionError):
+        get_output_type('test.bob')
+    with pytest.raises(AssertionError):
+        get_output_type('test')
+
+
+def test_list_parsers():
+    from tapir_amd.base import get_list_from_ints, get_list_from_ranges, get_strings_from_items
+    assert get_list_from_ints('1,2,3') == [1, 2, 3]
+    assert get_strings_from_items('1,2,3') == ['1', '2', '3']
+    assert get_list_from_ranges('1-2,2-3,3-4') == [[1, 2], [2, 3], [3, 4]]
+    with pytest.raises(argparse.ArgumentTypeError):
+        get_list_from_ints('1,b')
+    with pytest.raises(argparse.ArgumentTypeError):
+        get_list_from_ranges('1-x')
+
+
+def test_get_files(golden_dir, tmp_path):
+    from tapir_amd.base import get_files
+    for f in ("chr1_918.nex", "informativeness_cutoff.nex"):
+        shutil.copy(os.path.join(golden_dir, f), tmp_path)
+    (tmp_path / "test-extension.nexus").write_text("")
+    observed = [os.path.basename(i) for i in get_files(str(tmp_path), '*.nex,*.nexus')]
+    assert set(observed) == {'chr1_918.nex', 'informativeness_cutoff.nex', 'test-extension.nexus'}
+    with pytest.raises(IOError):
+        get_files('test-data', '*.rrwrr')
+
+
+def test_create_unique_dir(tmp_path):
+    from tapir_amd.base import create_unique_dir
+    d = tmp_path / "out"
+    d.mkdir()
+    assert create_unique_dir(str(d)) == str(d)          # empty: used as is
+    (d / "x").write_text("1")
+    assert create_unique_dir(str(d)) == str(d) + ".1"   # non-empty: sibling .1
+    assert create_unique_dir(str(d)) == str(d) + ".2"
+
+
+def test_parse_subset_map_file(tmp_path):
+    from tapir_amd.base import parse_subset_map_file
+    p = tmp_path / "m.tsv"
+    p.write_text("a.nex\t0\t10\n\nb.nex\t5\t7\n")
+    assert dict(parse_subset_map_file(str(p))) == {"a.nex": [0, 10], "b.nex": [5, 7]}
+
+
+# ---- trees and alignments ---------------------------------------------------------------------------
+def test_tree_adjustment_matches_reference_test(golden_dir, tmp_path):
+    """TestTreeAdjustment (test_compute.py:76-91): Euteleost.tree / 100."""
+    from tapir_amd import compute, newick
+    depth, factor, pth = compute.correct_branch_lengths(os.path.join(golden_dir, 'Euteleost.tree'), 'newick', d=str(tmp_path))
+    assert depth == 174.0 and factor == 100
+    assert os.path.basename(pth) == "Tree_100_174.0.newick"
+    got = newick.read_tree(pth)
+    exp = newick.parse('(danRer6:1.74,(oryLat2:1,(gasAcu1:0.93,(fr2:0.37,tetNig2:0.37):0.56):0.07):0.74);')
+    ga, ea = newick.postorder(got), newick.postorder(exp)
+    assert [n.name for n in ga] == [n.name for n in ea]
+    assert np.allclose([n.length or 0 for n in ga], [n.length or 0 for n in ea], rtol=0, atol=1e-15)
+
+
+def test_newick_roundtrip_and_errors():
+    from tapir_amd import newick
+    t = "((a:1.5,'b c':2):0.25,(d:1e-3,e:3,f:4)g:1)root;"
+    root = newick.parse(t)
+    assert [n.name for n in newick.leaves(root)] == ["a", "b c", "d", "e", "f"]
+    assert abs(newick.tree_length(root) - (1.5 + 2 + .25 + 1e-3 + 3 + 4 + 1)) < 1e-12
+    again = newick.parse(newick.write(root))
+    assert newick.write(again) == newick.write(root)
+    for bad in ("", "a,b;", "((a,b);", "(a,b));"):
+        with pytest.raises(newick.NewickError):
+            newick.parse(bad)
+
+
+def test_nexus_tree_file(tmp_path):
+    from tapir_amd import newick
+    p = tmp_path / "t.nex"
+    p.write_text("#NEXUS\nbegin trees;\n translate 1 alpha, 2 beta, 3 gamma;\n tree one = [&R] ((1:1,2:1):1,3:2);\nend;\n")
+    root = newick.read_tree(str(p), "nexus")
+    assert [n.name for n in newick.leaves(root)] == ["alpha", "beta", "gamma"]
+    assert newick.distance_from_tip(root) == 2.0
+
+
+def test_nexus_matrix_and_masks(golden_dir, tmp_path):
+    from tapir_amd import compute, nexus
+    names, st = nexus.read_states(os.path.join(golden_dir, "chr1_918.nex"))
+    assert names == ["danRer6", "fr2", "oryLat2", "gasAcu1", "tetNig2"] and st.shape == (5, 226)
+    assert set(np.unique(st)) <= {1, 2, 4, 8, 15}
+    exp = np.load(os.path.join(golden_dir, "chr1_918-test-cutoff-values.npy"))
+    got = compute.get_informative_sites(os.path.join(golden_dir, "chr1_918.nex"), 3)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    small = compute.get_informative_sites(os.path.join(golden_dir, "informativeness_cutoff.nex"), 3)
+    assert np.isnan(small[:2]).all() and np.array_equal(small[2:], [1.0, 1.0])
+    # interleaved + ambiguity codes + lowercase
+    p = tmp_path / "i.nex"
+    p.write_text("#NEXUS\nbegin data;\n dimensions ntax=2 nchar=6;\n format datatype=dna missing=? gap=- interleave;\n"
+                 "matrix\n a ACg\n b R?-\n\n a TNY\n b ttt\n;\nend;\n")
+    names, st = nexus.read_states(str(p))
+    assert st.tolist() == [[1, 2, 4, 8, 15, 10], [5, 15, 15, 8, 8, 8]]
+    with pytest.raises(nexus.NexusError):
+        nexus.read_matrix(os.path.join(str(tmp_path), "i.nex").replace("i.nex", "missing.nex")) if False else nexus.encode(["AZ"])
+    empty = tmp_path / "e.nexus"
+    empty.write_text("")
+    with pytest.raises(nexus.NexusError):
+        nexus.read_matrix(str(empty))
+
+
+def test_base_frequencies_match_fixture_header(golden_dir):
+    """HarvestFrequencies counts a gap as 1/4 of each base: gives the PhyDesign header 0.14/0.19/0.33/0.34."""
+    from tapir_amd import nexus
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    names, st = nexus.read_states(os.path.join(golden_dir, "chr1_918.nex"))
+    pi = nexus.base_frequencies_from_histogram(oracle_engine.state_histogram(st, [0, 226]))[0]
+    # 0.137/0.187/0.329/0.346 (gap-free counting would give 0.112/0.173/0.347/0.368)
+    assert np.allclose(pi, [0.13738938, 0.1869469, 0.32942478, 0.34623894], atol=1e-8)
+    assert np.abs(pi - np.array([0.14, 0.19, 0.33, 0.34])).max() < 0.0065
+
+
+def test_parse_site_rates_and_cull(golden_dir, tmp_path):
+    """TestTransform (test_compute.py:19-36) with real comparisons, and the rewrite with corrected_rates."""
+    from tapir_amd import compute
+    src = os.path.join(golden_dir, "test-uniform-draw-weights.rates.json")
+    exp = np.load(os.path.join(golden_dir, "test-parsed-rates.npy")).ravel()
+    assert np.array_equal(compute.parse_site_rates(src, test=True), exp)
+    assert np.array_equal(compute.parse_site_rates(src, 10., test=True), exp / 10.)
+    cp = tmp_path / "x.rates"
+    shutil.copy(src, cp)
+    got = compute.parse_site_rates(str(cp), correction=100)
+    doc = json.load(open(cp))
+    assert [d["site"] for d in doc["sites"]["corrected_rates"]] == list(range(1, 101))
+    assert np.array_equal([d["rate"] for d in doc["sites"]["corrected_rates"]], got)
+    mask = np.load(os.path.join(golden_dir, "chr1_918-test-cutoff-values.npy"))[:100]
+    culled = compute.cull_uninformative_rates(compute.parse_site_rates(src, 10., test=True), mask)
+    expc = np.load(os.path.join(golden_dir, "test-culled-rates.npy"))
+    assert np.array_equal(np.isnan(culled), np.isnan(expc)) and np.array_equal(culled[~np.isnan(culled)], expc[~np.isnan(expc)])
+    t = compute.get_time(0, 5)
+    assert t.shape == (5, 1) and t.ravel().tolist() == [0, 1, 2, 3, 4]
+
+
+# ---- tree program (host half of the kernel) ----------------------------------------------------------
+def test_tree_program_shapes():
+    """The compiled traversal: op counts and Sethi-Ullman stack depth for known shapes, via the C ABI is not
+    possible without a GPU, so the same invariants are checked on the oracle-side arrays."""
+    from tapir_amd import newick, synth
+    root, names = synth.yule_tree(64, 1)
+    parent, blen, leaf = newick.to_arrays(root, names)
+    assert (parent[:-1] > np.arange(len(parent) - 1)).all() and parent[-1] == -1
+    assert sorted(leaf[leaf >= 0].tolist()) == list(range(64))
+    assert abs(newick.distance_from_tip(root) - 100.0) < 1e-9
+    pin = synth.plan_inputs(root, names)
+    assert pin["T"] == 100 and pin["correction"] == 100
+
+
+# ---- sqlite and the CLI end to end (oracle-backed engine) ----------------------------------------------
+REF_SCHEMA = [
+    "CREATE TABLE loci (id INTEGER PRIMARY KEY AUTOINCREMENT, locus TEXT)",
+    "CREATE TABLE net (id INT, time INT, pi FLOAT,\n            FOREIGN KEY(id) REFERENCES loci(id) DEFERRABLE INITIALLY\n            DEFERRED)",
+    "CREATE TABLE discrete (id INT, time INT, pi FLOAT, \n            FOREIGN KEY(id) REFERENCES loci(id) DEFERRABLE INITIALLY\n            DEFERRED)",
+    "CREATE TABLE interval (id INT, interval TEXT, pi FLOAT,\n            error FLOAT, FOREIGN KEY(id) REFERENCES loci(id) DEFERRABLE\n            INITIALLY DEFERRED)",
+]
+
+
+def _run_cli(golden_dir, tmp_path, extra=(), engine_mod=None):
+    from tapir_amd import cli
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    shutil.copy(os.path.join(golden_dir, "chr1_918.nex"), aln)
+    out = tmp_path / "out"
+    out.mkdir()
+    argv = [str(aln), os.path.join(golden_dir, "Euteleost.tree"), "--output", str(out), "--times", "10,20,50",
+            "--intervals", "0-10,10-15,20-100", "--exchangeabilities", "0.96,1,0.58,0.36,1.87,0.51"] + list(extra)
+    return cli.main(argv, engine_mod=engine_mod), aln
+
+
+def check_cli_outputs(outdir, oracle, golden_dir):
+    files = sorted(os.listdir(outdir))
+    assert files == ["Tree_100_174.0.newick", "chr1_918.nex.rates", "phylogenetic-informativeness.sqlite"]
+    doc = json.load(open(os.path.join(outdir, "chr1_918.nex.rates")))
+    assert list(doc.keys()) == ["sites"]
+    assert set(doc["sites"].keys()) == {"freqs", "subs_matrix", "rates", "corrected_rates"}
+    assert set(doc["sites"]["freqs"]) == set("ACGT") and set(doc["sites"]["subs_matrix"]) == {"AC", "AG", "AT", "CG", "CT", "GT"}
+    rows = doc["sites"]["rates"]
+    assert [r["site"] for r in rows] == list(range(1, 227)) and set(rows[0]) == {"site", "subst", "rate", "ll"}
+    for r in rows[:40]:
+        for k in ("subst", "rate", "ll"):
+            assert abs(r[k] * 1e4 - round(r[k] * 1e4)) < 1e-6  # 4 decimals, Format(x,0,4)
+    # values: empirical pi (unrounded) + the fixture's exchangeabilities -> same numbers as the oracle
+    from tapir_amd import newick, nexus
+    names, st = nexus.read_states(os.path.join(golden_dir, "chr1_918.nex"))
+    root = newick.read_tree(os.path.join(outdir, "Tree_100_174.0.newick"))
+    leaf_names = [n.name for n in newick.leaves(root)]
+    parent, blen, leaf = newick.to_arrays(root, leaf_names)
+    st = st[[names.index(n) for n in leaf_names]]
+    pi = np.array([doc["sites"]["freqs"][b] for b in "ACGT"])
+    ref = oracle.site_rates(st, parent, blen, leaf, pi, [0.96, 1, 0.58, 0.36, 1.87, 0.51])
+    ok = (ref["flag"] == 0) | (ref["flag"] == 3)
+    assert np.abs(np.array([r["rate"] for r in rows]) - ref["rate"])[ok].max() < 5.1e-5
+    assert np.abs(np.array([r["ll"] for r in rows]) - ref["lnl"]).max() < 5.1e-5
+    corr = np.array([r["rate"] for r in doc["sites"]["corrected_rates"]])
+    assert np.array_equal(corr, np.array([r["rate"] for r in rows]) / 100)
+    # sqlite: byte-identical DDL, row counts, values vs the numpy/scipy restatement of worker()
+    conn = sqlite3.connect(os.path.join(outdir, "phylogenetic-informativeness.sqlite"))
+    schema = [r[0] for r in conn.execute("select sql from sqlite_master where type='table' and name!='sqlite_sequence' order by rowid")]
+    assert schema == REF_SCHEMA
+    assert conn.execute("select locus from loci").fetchall() == [("chr1_918",)]
+    net = conn.execute("select time, pi from net order by time").fetchall()
+    assert [t for t, _ in net] == list(range(174))
+    rates = corr.copy()
+    rates[ref["nres"] < 3] = np.nan
+    pi_net, pi_times, pi_epochs = oracle.worker_tables(rates, 174, [10, 20, 50], [[0, 10], [10, 15], [20, 100]])
+    assert np.allclose([p for _, p in net], pi_net, rtol=1e-9, atol=1e-300)
+    disc = dict(conn.execute("select time, pi from discrete").fetchall())
+    assert set(disc) == {10, 20, 50} and all(abs(disc[t] - pi_times[t]) <= 1e-9 * abs(pi_times[t]) for t in disc)
+    iv = {k: (p, e) for k, p, e in conn.execute("select interval, pi, error from interval")}
+    assert set(iv) == {"0-10", "10-15", "20-100"}
+    for k in iv:
+        assert abs(iv[k][0] - pi_epochs[k]["sum(integral)"]) <= 1e-9 * pi_epochs[k]["sum(integral)"]
+        assert abs(iv[k][1] - pi_epochs[k]["sum(error)"]) <= 1e-4 * pi_epochs[k]["sum(error)"]  # abserr is partly rounding noise
+    conn.close()
+
+
+def test_cli_end_to_end_with_oracle_engine(golden_dir, tmp_path, oracle, capsys):
+    """BASELINE config C1 plumbing: bundled locus + tree through the CLI; engine = CPU oracle stand-in."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    outdir, aln = _run_cli(golden_dir, tmp_path, engine_mod=oracle_engine)
+    check_cli_outputs(outdir, oracle, golden_dir)
+    # --site-rates re-analysis of the files just written (bin/tapir_compute.py:153-158): no cull, divides again
+    from tapir_amd import cli
+    rates_dir = tmp_path / "rates"
+    rates_dir.mkdir()
+    shutil.copy(os.path.join(outdir, "chr1_918.nex.rates"), rates_dir)
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    cli.main([str(rates_dir), os.path.join(golden_dir, "Euteleost.tree"), "--output", str(out2), "--times", "10",
+              "--intervals", "0-10", "--site-rates"], engine_mod=oracle_engine)
+    conn = sqlite3.connect(os.path.join(str(out2), "phylogenetic-informativeness.sqlite"))
+    assert conn.execute("select locus from loci").fetchall() == [("chr1_918.nex",)]  # one extension stripped
+    doc = json.load(open(rates_dir / "chr1_918.nex.rates"))
+    r = np.array([x["rate"] for x in doc["sites"]["rates"]]) / 100
+    net10 = conn.execute("select pi from net where time=10").fetchone()[0]
+    assert abs(net10 - np.nansum(oracle.get_townsend_pi(10, r))) <= 1e-9 * net10
+    conn.close()
+
+
+def test_cli_subset_map(golden_dir, tmp_path, oracle):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    m = tmp_path / "map.tsv"
+    m.write_text("chr1_918.nex\t50\t150\n")
+    outdir, _ = _run_cli(golden_dir, tmp_path, extra=["--subset-pi-map-file", str(m)], engine_mod=oracle_engine)
+    doc = json.load(open(os.path.join(outdir, "chr1_918.nex.rates")))
+    from tapir_amd import nexus
+    _, st = nexus.read_states(os.path.join(golden_dir, "chr1_918.nex"))
+    inf = ((st == 1) | (st == 2) | (st == 4) | (st == 8)).sum(axis=0) >= 3
+    r = np.array([x["rate"] for x in doc["sites"]["corrected_rates"]])
+    r[~inf] = np.nan
+    r = r[50:150]
+    conn = sqlite3.connect(os.path.join(outdir, "phylogenetic-informativeness.sqlite"))
+    net20 = conn.execute("select pi from net where time=20").fetchone()[0]
+    assert abs(net20 - np.nansum(oracle.get_townsend_pi(20, r))) <= 1e-9 * net20
+
+
+def test_cli_rejects_bad_input(golden_dir, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    with pytest.raises(IndexError):  # --times beyond the tree depth: numpy IndexError in the reference too
+        _run_cli(golden_dir, tmp_path, extra=["--times", "500"], engine_mod=oracle_engine)
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------
+def test_cabi_exports_every_declared_symbol():
+    """libtphip.so loads without a GPU and exports exactly what include/tphip.h declares."""
+    import __graft_entry__ as ge
+    ge.build()
+    from tapir_amd import engine
+    header = open(os.path.join(ROOT, "include", "tphip.h")).read()
+    declared = set(re.findall(r"\b(tphip_[a-z_0-9]+)\s*\(", header))
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    bound = {s[0] for s in engine.SYMBOLS}
+    assert bound == declared, (bound ^ declared)
+    nm = subprocess.run(["nm", "-D", "--defined-only", engine.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (tphip_[a-z_0-9]+)$", nm, flags=re.M))
+    assert exported == declared, (exported ^ declared)
+    assert lib.tphip_version() == 100
+
+
+def test_engine_fails_loudly_without_gpu(chr1_918):
+    """No silent CPU fallback: on a GPU-less machine plan creation raises with TPHIP_ERR_NO_DEVICE."""
+    from tapir_amd import engine
+    if engine.device_count() > 0:
+        pytest.skip("GPU present")
+    c = chr1_918
+    with pytest.raises(engine.TphipError, match="no HIP device"):
+        engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, 226], [c["pi"]], [c["exch"]], 174, [10], [[0, 10]])
+    with pytest.raises(engine.TphipError, match="no HIP device"):
+        engine.townsend_pi_dense([1.0], [0.1])
+
+
+# ---- multi-rank: loci round-robin + one all-gather (gloo, world_size 2) -------------------------------
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch
+from tapir_amd import dist as tdist, synth
+import oracle_engine
+rank, world = tdist.init_process_group("gloo")
+nloci, ncols, ntaxa = 7, 40, 6
+d = synth.simulate(nloci, ncols, ntaxa, 99)
+pin = synth.plan_inputs(d["root"], d["names"])
+st = d["states"].numpy()
+mine = tdist.shard_loci(nloci, rank, world)
+cols = np.concatenate([np.arange(l * ncols, (l + 1) * ncols) for l in mine])
+off = np.arange(len(mine) + 1) * ncols
+plan = oracle_engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, d["pi"][mine], d["exch"][mine], pin["T"],
+                          [10, 30], [[5, 15]], correction=pin["correction"])
+local = torch.from_numpy(plan.run_fused(st[:, cols])["tables"])
+full = tdist.gather_tables(local, nloci, rank, world)
+np.save(os.path.join(%(out)r, "rank%%d.npy" %% rank), full.numpy())
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_sharded_tables_gloo_world2(tmp_path):
+    import torch  # noqa: F401
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % {"root": ROOT, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(a, b) and a.shape[0] == 7
+    # single-process answer over all loci, same engine
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    from tapir_amd import synth
+    d = synth.simulate(7, 40, 6, 99)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    plan = oracle_engine.Plan(6, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"],
+                              [10, 30], [[5, 15]], correction=pin["correction"])
+    full = plan.run_fused(d["states"].numpy())["tables"]
+    assert np.array_equal(a, full)  # bit-identical: a locus' row does not depend on the sharding
