@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage: scratch/pmc.sh <tag> [bench args...]   (run on the GPU box from the repo root)
+set -u
+TAG=$1; shift
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp
+i=0
+for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" \
+         "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_THREAD_CYCLES_VALU" \
+         "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INSTS_VALU_TRANS_F64" \
+         "GRBM_GUI_ACTIVE SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_BRANCH SQ_IFETCH" \
+         "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<PY
+import csv, glob, collections
+tot = collections.defaultdict(float); n = collections.defaultdict(int)
+for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "site_rate_kernel" in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+for k in sorted(tot): print(k, tot[k] / max(1, n[k]), "(avg over", n[k], "dispatches)")
+PY
+rm -rf $OUT/p[0-9]*

@@ -14,15 +14,16 @@
 
 namespace tphip {
 
+// Packed to the 32 doubles the kernels actually read (eigenvalue 0 and its trivial eigenvectors are implicit),
+// so a wave can hold the whole model in 64 SGPRs instead of re-fetching it in every tree op.
 struct LocusModel {
-    double lam[4];   // lam[0] == 0
-    double U[16];    // row-major U[i*4+k];   U[i*4+0] == 1
-    double Ui[16];   // row-major Ui[k*4+j];  Ui[0*4+j] == pi[j]
+    double lam[3];   // lam_1..lam_3 (all < 0); lam_0 == 0 is implicit
+    double U[12];    // U[i*3 + (k-1)], k = 1..3;      U[i][0] == 1 is implicit
+    double Ui[12];   // Ui[(k-1)*4 + j], k = 1..3;     U^-1[0][j] == pi[j]
     double pi[4];
     double kappa;
-    double pad[7];   // 48 doubles = 384 B: keeps every model 128-B aligned for scalar loads
 };
-static_assert(sizeof(LocusModel) == 384, "LocusModel layout");
+static_assert(sizeof(LocusModel) == 256, "LocusModel layout");
 
 __global__ void gtr_setup_kernel(const double* __restrict__ pi_in, const double* __restrict__ exch_in, int64_t nloci,
                                  LocusModel* __restrict__ models) {
@@ -65,18 +66,16 @@ __global__ void gtr_setup_kernel(const double* __restrict__ pi_in, const double*
     int order[4] = {z, 0, 0, 0};
     for (int k = 0, o = 1; k < 4; ++k) if (k != z) order[o++] = k;
     LocusModel m;
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 1; o < 4; ++o) {
         int k = order[o];
-        m.lam[o] = A[k][k];
+        m.lam[o - 1] = A[k][k];
         for (int i = 0; i < 4; ++i) {
-            m.U[i * 4 + o] = V[i][k] / sq[i];
-            m.Ui[o * 4 + i] = V[i][k] * sq[i];
+            m.U[i * 3 + (o - 1)] = V[i][k] / sq[i];
+            m.Ui[(o - 1) * 4 + i] = V[i][k] * sq[i];
         }
     }
-    m.lam[0] = 0.0;
-    for (int i = 0; i < 4; ++i) { m.U[i * 4 + 0] = 1.0; m.Ui[0 * 4 + i] = pi[i]; m.pi[i] = pi[i]; }
+    for (int i = 0; i < 4; ++i) m.pi[i] = pi[i];
     m.kappa = kappa;
-    for (int i = 0; i < 7; ++i) m.pad[i] = 0;
     models[l] = m;
 }
 

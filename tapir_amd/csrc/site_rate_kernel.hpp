@@ -5,11 +5,15 @@
 // of the fixed tree (bf:1003-1013), GTR model (bf:978-1001), start value 1 (bf:1050).
 //
 // Mapping to CDNA4
-//   * one alignment column per lane, 64 columns (one wavefront) per workgroup, all of one locus, so the
-//     locus' eigen-system and the tree program are wave-uniform: they live in SGPRs / the scalar cache and
-//     enter the FP64 VALU instructions as scalar operands;
+//   * one alignment column per lane, one wavefront per workgroup, all of one locus, so the locus'
+//     eigen-system (32 doubles) and the tree program are wave-uniform: they live in SGPRs / the scalar
+//     cache and enter the FP64 VALU instructions as scalar operands;
 //   * the traversal is the uniform op stream of tree_program.hpp -- no lane divergence inside a likelihood
-//     evaluation; lanes diverge only in how many Newton steps they need;
+//     evaluation; lanes differ only in how many Newton steps they need, and a lane whose column has
+//     converged immediately takes the next column of the wave's work slice (lane refill), so the wave
+//     keeps 64 live columns until its slice runs dry;
+//   * the next op and the next tip's state byte are fetched one op ahead (scalar load / global byte load
+//     in flight under the current op's ~10^3 cycles of FP64 work);
 //   * the running partial (value, d/du, d2/du2 of the 4 conditional likelihoods; u = log siteRate) is 12
 //     doubles in VGPRs; parked siblings go to an LDS stack laid out [slot][component][lane] so every
 //     ds_read/write_b64 is a conflict-free 512-B row;
@@ -33,7 +37,8 @@ constexpr double kStepMax = 2.0;
 constexpr double kStepTol = 1e-9;
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
-constexpr int kSiteBlock = 64;  // one wavefront per workgroup
+constexpr int kSiteBlock = 64;      // one wavefront per workgroup
+constexpr int kSiteLdsHeader = 96;  // doubles of LDS before the stack: tip table [16][4] + model [32]
 
 struct SiteParams {
     const uint8_t* states;       // [ntaxa][ncols_total]
@@ -44,8 +49,9 @@ struct SiteParams {
     int32_t stack_depth;
     double chrono_length;
     const int64_t* locus_offsets;  // [nloci+1]
-    const int32_t* chunk_locus;    // [nchunks]  64-column chunks, never straddling loci
-    const int32_t* chunk_index;    // [nchunks]  index of the chunk inside its locus
+    const int32_t* chunk_locus;    // [nchunks]  work slices of chunk_cols columns, never straddling loci
+    const int32_t* chunk_index;    // [nchunks]  index of the slice inside its locus
+    int32_t chunk_cols;            // columns per slice (multiple of 64)
     const int32_t* work_cols;      // [ncols_total] compacted column ids, per locus at locus_offsets[l]
     const int32_t* work_count;     // [nloci]
     double* rate;
@@ -59,9 +65,9 @@ struct Partial {  // value and first/second derivative (wrt u) of the 4 conditio
     double v[4], d1[4], d2[4];
 };
 
-// exp(x) for x <= 0 (branch exponents lam*t*s are never positive).  Cody-Waite reduction + degree-11
-// Taylor/minimax-equivalent polynomial on |r| <= ln2/2; 2^n applied through the exponent field.
-// Max observed error vs libm < 1 ulp-ish on [-745, 0]; results below 2^-1022 flush to 0.
+// exp(x) for x <= 0 (branch exponents lam*t*s are never positive).  Cody-Waite reduction + degree-13
+// Taylor polynomial on |r| <= ln2/2 (truncation < 4e-18); 2^n applied through the exponent field.
+// Error vs libm <= 1 ulp on [-708, 0]; results below 2^-1021 flush to 0.
 __device__ __forceinline__ double exp_nonpos(double x) {
     const double LOG2E = 1.4426950408889634074;
     const double LN2_HI = 6.93147180369123816490e-01;
@@ -69,7 +75,6 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     double n = rint(x * LOG2E);
     double r = fma(-n, LN2_HI, x);
     r = fma(-n, LN2_LO, r);
-    // exp(r) = 1 + r + r^2/2! + ... + r^13/13!   (|r| <= 0.3466: truncation < 2e-18)
     double p = 1.6059043836821613e-10;          // 1/13!
     p = fma(p, r, 2.08767569878681e-09);        // 1/12!
     p = fma(p, r, 2.505210838544172e-08);       // 1/11!
@@ -85,10 +90,9 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
     int ni = (int)n;
-    if (ni < -1021) return 0.0;  // below the normal range: contributes nothing to any likelihood here
-    // multiply by 2^ni through the exponent bits (p in [0.70, 1.42], result stays normal)
-    long long bits = __double_as_longlong(p) + ((long long)ni << 52);
-    return __longlong_as_double(bits);
+    // multiply by 2^ni through the exponent bits (p in [0.70, 1.42], result stays normal for ni >= -1021)
+    long long bits = __double_as_longlong(p) + (long long)((unsigned long long)(long long)ni << 52);
+    return (ni < -1021) ? 0.0 : __longlong_as_double(bits);
 }
 
 // acc *= m (product rule for value / first / second derivative)
@@ -103,13 +107,34 @@ __device__ __forceinline__ void partial_mul(Partial& a, const Partial& m) {
     }
 }
 
+// The locus' model as plain scalars (wave-uniform: the compiler keeps them in SGPRs).
+struct ModelRegs {
+    double lam[3], U[12], Ui[12], pi[4];
+};
+
+// The 31 doubles go through LDS so that they land in VGPRs (replicated across lanes): 62 SGPRs of model
+// plus the op pipeline and pointers do not fit the scalar file, and the resulting SGPR spills (v_readlane /
+// s_mov traffic in every op) cost more issue slots than 62 VGPRs do at the 2 waves/SIMD the LDS stack allows.
+__device__ __forceinline__ ModelRegs load_model(const LocusModel* __restrict__ M, double* mtab, int lane) {
+    if (lane < 32) mtab[lane] = reinterpret_cast<const double*>(M)[lane];  // lam[3] U[12] Ui[12] pi[4] kappa
+    __syncthreads();
+    ModelRegs R;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) R.lam[i] = mtab[i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { R.U[i] = mtab[3 + i]; R.Ui[i] = mtab[15 + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R.pi[i] = mtab[27 + i];
+    return R;
+}
+
 // message of a tip through its branch: P(t s) * tip, with derivatives wrt u = log s.
 // w[k] = (U^-1 tip)_k from the LDS mask table; x_k = lam_k t s; e_k = exp(x_k).
-__device__ __forceinline__ void tip_message(const LocusModel* __restrict__ M, const double* w, double ts, Partial& m) {
+__device__ __forceinline__ void tip_message(const ModelRegs& R, const double* w, double ts, Partial& m) {
     double a[3], b[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        double x = M->lam[k + 1] * ts;
+        double x = R.lam[k] * ts;
         double e = exp_nonpos(x);
         a[k] = e * w[k + 1];
         b[k] = x * a[k];
@@ -117,19 +142,22 @@ __device__ __forceinline__ void tip_message(const LocusModel* __restrict__ M, co
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const double* Ur = M->U + i * 4;
-        m.v[i] = fma(Ur[3], a[2], fma(Ur[2], a[1], fma(Ur[1], a[0], w[0])));
-        m.d1[i] = fma(Ur[3], b[2], fma(Ur[2], b[1], Ur[1] * b[0]));
-        m.d2[i] = fma(Ur[3], c[2], fma(Ur[2], c[1], Ur[1] * c[0]));
+        const double* Ur = R.U + i * 3;
+        m.v[i] = fma(Ur[2], a[2], fma(Ur[1], a[1], fma(Ur[0], a[0], w[0])));
+        m.d1[i] = fma(Ur[2], b[2], fma(Ur[1], b[1], Ur[0] * b[0]));
+        m.d2[i] = fma(Ur[2], c[2], fma(Ur[1], c[1], Ur[0] * c[0]));
     }
 }
 
 // acc <- P(t s) * acc with derivatives (internal branch)
-__device__ __forceinline__ void branch_apply(const LocusModel* __restrict__ M, double ts, Partial& p) {
+__device__ __forceinline__ void branch_apply(const ModelRegs& R, double ts, Partial& p) {
     double w0[4], w1[4], w2[4];
+    w0[0] = fma(R.pi[3], p.v[3], fma(R.pi[2], p.v[2], fma(R.pi[1], p.v[1], R.pi[0] * p.v[0])));
+    w1[0] = fma(R.pi[3], p.d1[3], fma(R.pi[2], p.d1[2], fma(R.pi[1], p.d1[1], R.pi[0] * p.d1[0])));
+    w2[0] = fma(R.pi[3], p.d2[3], fma(R.pi[2], p.d2[2], fma(R.pi[1], p.d2[1], R.pi[0] * p.d2[0])));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double* Ir = M->Ui + k * 4;
+    for (int k = 1; k < 4; ++k) {
+        const double* Ir = R.Ui + (k - 1) * 4;
         w0[k] = fma(Ir[3], p.v[3], fma(Ir[2], p.v[2], fma(Ir[1], p.v[1], Ir[0] * p.v[0])));
         w1[k] = fma(Ir[3], p.d1[3], fma(Ir[2], p.d1[2], fma(Ir[1], p.d1[1], Ir[0] * p.d1[0])));
         w2[k] = fma(Ir[3], p.d2[3], fma(Ir[2], p.d2[2], fma(Ir[1], p.d2[1], Ir[0] * p.d2[0])));
@@ -137,7 +165,7 @@ __device__ __forceinline__ void branch_apply(const LocusModel* __restrict__ M, d
     double a[3], b[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        double x = M->lam[k + 1] * ts;
+        double x = R.lam[k] * ts;
         double e = exp_nonpos(x);
         a[k] = e * w0[k + 1];
         double ew1 = e * w1[k + 1], ew2 = e * w2[k + 1];
@@ -146,10 +174,10 @@ __device__ __forceinline__ void branch_apply(const LocusModel* __restrict__ M, d
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const double* Ur = M->U + i * 4;
-        p.v[i] = fma(Ur[3], a[2], fma(Ur[2], a[1], fma(Ur[1], a[0], w0[0])));
-        p.d1[i] = fma(Ur[3], b[2], fma(Ur[2], b[1], fma(Ur[1], b[0], w1[0])));
-        p.d2[i] = fma(Ur[3], c[2], fma(Ur[2], c[1], fma(Ur[1], c[0], w2[0])));
+        const double* Ur = R.U + i * 3;
+        p.v[i] = fma(Ur[2], a[2], fma(Ur[1], a[1], fma(Ur[0], a[0], w0[0])));
+        p.d1[i] = fma(Ur[2], b[2], fma(Ur[1], b[1], fma(Ur[0], b[0], w1[0])));
+        p.d2[i] = fma(Ur[2], c[2], fma(Ur[1], c[1], fma(Ur[0], c[0], w2[0])));
     }
 }
 
@@ -165,58 +193,83 @@ __device__ __forceinline__ void partial_rescale(Partial& p, int& scale) {
     }
 }
 
-// One likelihood evaluation for this lane's column: f = log L, g = df/du, h = d2f/du2 at u (s = exp(u)).
-__device__ __forceinline__ void evaluate_column(const SiteParams& P, const LocusModel* __restrict__ M,
-                                                const double* __restrict__ wtab, double* __restrict__ stack,
-                                                int64_t col, double s, double& f, double& g, double& h) {
+__device__ __forceinline__ unsigned load_state(const SiteParams& P, int taxon, int64_t col) {
+    return P.states[(int64_t)taxon * P.ncols_total + col];
+}
+
+// One likelihood evaluation for this lane's column: f = log L, g = df/du, h = d2f/du2 at s = exp(u).
+__device__ __forceinline__ void evaluate_column(const SiteParams& P, const ModelRegs& R, const double* __restrict__ wtab,
+                                                double* __restrict__ stack, int64_t col, double s, double& f,
+                                                double& g, double& h) {
     Partial acc;
     int scale = 0;
     int sp = 0;
     const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc.v[i] = 1.0; acc.d1[i] = 0.0; acc.d2[i] = 0.0; }
+    // The op stream is read through the constant address space: it is never written while the kernel runs,
+    // and this is what lets the compiler use scalar loads (s_load) although the kernel also stores results.
+    typedef const TreeOp __attribute__((address_space(4))) * ConstOps;
+    ConstOps ops = (ConstOps)(uintptr_t)P.ops;
+    const int last = P.nops - 1;
+    TreeOp op, nxt;
+    op.code = ops[0].code; op.taxon = ops[0].taxon; op.t = ops[0].t;
+    { const int i1 = last < 1 ? last : 1; nxt.code = ops[i1].code; nxt.taxon = ops[i1].taxon; nxt.t = ops[i1].t; }
+    unsigned st = load_state(P, op.taxon, col);  // the program always starts at a tip
     for (int ip = 0; ip < P.nops; ++ip) {
-        const TreeOp op = P.ops[ip];  // uniform address -> scalar load
-        if (op.code <= OP_TIP_MUL) {
-            unsigned mask = P.states[(int64_t)op.taxon * P.ncols_total + col] & 15u;
-            mask = mask ? mask : 15u;
-            const double* w = wtab + mask * 4;
-            double wv[4] = {w[0], w[1], w[2], w[3]};
+        // Two-deep fetch pipeline: op ip+2 (scalar load) and the state byte of op ip+1 (global byte load) are
+        // issued here and consumed one iteration later, i.e. they stay in flight under this op's FP64 work.
+        TreeOp nn;
+        { const int i2 = (ip + 2 < last) ? ip + 2 : last; nn.code = ops[i2].code; nn.taxon = ops[i2].taxon; nn.t = ops[i2].t; }
+        unsigned st_nxt = 15u;
+        if (nxt.code <= OP_TIP_MUL) st_nxt = load_state(P, nxt.taxon, col);
+        if (op.code != OP_BRANCH && op.code != OP_PUSH) {
+            // acc *= m, with m the message of a tip (TIP_SET / TIP_MUL) or a parked sibling (POP_MUL).
+            // TIP_SET is TIP_MUL onto the identity: acc is the identity at program start and after every PUSH,
+            // which are the only places a subtree can begin (tree_program.hpp).
             Partial m;
-            tip_message(M, wv, op.t * s, m);
-            if (op.code == OP_TIP_SET) acc = m;
-            else { partial_rescale(acc, scale); partial_mul(acc, m); }
+            if (op.code == OP_POP_MUL) {
+                --sp;
+                const double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m.v[i] = slot[(i)*kSiteBlock];
+                    m.d1[i] = slot[(4 + i) * kSiteBlock];
+                    m.d2[i] = slot[(8 + i) * kSiteBlock];
+                }
+            } else {
+                unsigned mask = st & 15u;
+                mask = mask ? mask : 15u;
+                const double* w = wtab + mask * 4;
+                const double wv[4] = {w[0], w[1], w[2], w[3]};
+                tip_message(R, wv, op.t * s, m);
+            }
+            partial_rescale(acc, scale);
+            partial_mul(acc, m);
         } else if (op.code == OP_BRANCH) {
             partial_rescale(acc, scale);
-            branch_apply(M, op.t * s, acc);
-        } else if (op.code == OP_PUSH) {
+            branch_apply(R, op.t * s, acc);
+        } else {  // OP_PUSH: park the finished sibling, start the next subtree from the identity
             double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 slot[(i)*kSiteBlock] = acc.v[i];
                 slot[(4 + i) * kSiteBlock] = acc.d1[i];
                 slot[(8 + i) * kSiteBlock] = acc.d2[i];
+                acc.v[i] = 1.0; acc.d1[i] = 0.0; acc.d2[i] = 0.0;
             }
             ++sp;
-        } else {  // OP_POP_MUL
-            --sp;
-            const double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
-            Partial m;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                m.v[i] = slot[(i)*kSiteBlock];
-                m.d1[i] = slot[(4 + i) * kSiteBlock];
-                m.d2[i] = slot[(8 + i) * kSiteBlock];
-            }
-            partial_mul(acc, m);
         }
+        op = nxt;
+        nxt = nn;
+        st = st_nxt;
     }
     double L = 0, L1 = 0, L2 = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        L = fma(M->pi[i], acc.v[i], L);
-        L1 = fma(M->pi[i], acc.d1[i], L1);
-        L2 = fma(M->pi[i], acc.d2[i], L2);
+        L = fma(R.pi[i], acc.v[i], L);
+        L1 = fma(R.pi[i], acc.d1[i], L1);
+        L2 = fma(R.pi[i], acc.d2[i], L2);
     }
     double inv = 1.0 / L;
     g = L1 * inv;
@@ -224,47 +277,56 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Locus
     f = log(L) + (double)scale * 0.6931471805599453;
 }
 
+// tip table: wtab[mask][k] = sum_{j in mask} U^-1[k][j]   (row 0 of U^-1 is pi)
+__device__ __forceinline__ void build_tip_table(const LocusModel* __restrict__ M, double* wtab, int lane) {
+    int mask = lane >> 2, k = lane & 3;
+    double w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double uij = (k == 0) ? M->pi[j] : M->Ui[(k - 1) * 4 + j];
+        w += ((mask >> j) & 1) ? uij : 0.0;
+    }
+    wtab[lane] = w;
+}
+
 __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
     extern __shared__ double lds[];
     double* wtab = lds;          // [16 masks][4]
-    double* stack = lds + 64;    // [stack_depth][12][64]
+    double* mtab = lds + 64;     // [32] the locus' model
+    double* stack = lds + 96;    // [stack_depth][12][64]
     const int chunk = blockIdx.x;
     const int locus = P.chunk_locus[chunk];
-    const int cidx = P.chunk_index[chunk];
     const int count = P.work_count[locus];
-    if (cidx * kSiteBlock >= count) return;  // this chunk's columns were answered by classify_kernel
+    const int begin = P.chunk_index[chunk] * P.chunk_cols;
+    if (begin >= count) return;  // every column of this slice was answered by classify_kernel
+    const int end = min(count, begin + P.chunk_cols);
     const LocusModel* __restrict__ M = P.models + locus;
     const int lane = threadIdx.x;
-    {   // tip table: wtab[mask][k] = sum_{j in mask} Ui[k][j]
-        int mask = lane >> 2, k = lane & 3;
-        double w = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w += ((mask >> j) & 1) ? M->Ui[k * 4 + j] : 0.0;
-        wtab[lane] = w;
-    }
-    __syncthreads();
-    const int64_t loff = P.locus_offsets[locus];
-    const int widx = cidx * kSiteBlock + lane;
-    const bool active = widx < count;
-    const int64_t col = P.work_cols[loff + (active ? widx : cidx * kSiteBlock)];
+    build_tip_table(M, wtab, lane);
+    const ModelRegs R = load_model(M, mtab, lane);
+    const double kappa = mtab[31];
+    const int32_t* __restrict__ work = P.work_cols + P.locus_offsets[locus];
 
-    double u = 0.0, lo = kUMin, hi = kUMax, f = 0.0;
-    bool lo_open = true, hi_open = true, done = !active;
-    uint8_t flg = TPHIP_FLAG_MAXIT;
+    int next = begin + kSiteBlock;  // wave-uniform: first work index not yet handed to a lane
+    bool done = (begin + lane >= end);
+    int64_t col = work[done ? begin : begin + lane];
+    double u = 0.0, lo = kUMin, hi = kUMax;
+    bool lo_open = true, hi_open = true;
+    int it = 0;
     unsigned evals = 0;
-    for (int it = 0; it < kMaxIt; ++it) {
-        if (__all(done)) break;
-        double fe, g, h;
-        evaluate_column(P, M, wtab, stack, col, exp(u), fe, g, h);
+    while (true) {
+        double f, g, h;
+        evaluate_column(P, R, wtab, stack, col, exp(u), f, g, h);
         if (!done) {
             ++evals;
-            f = fe;
+            ++it;
+            int flg = -1;
             const bool uphill = !(g <= 0.0);
             // Saturation: beyond this point g is second-order small under first-order rounding noise, its
             // sign is meaningless; report the policy value s = 1e4 (same rule as the oracle).
-            if (fabs(g) < kFlatEps && fabs(h) < kFlatEps) { flg = TPHIP_FLAG_SATURATED; u = kUMax; done = true; }
-            else if (u >= kUMax && uphill) { flg = TPHIP_FLAG_SATURATED; done = true; }
-            else if (u <= kUMin && !uphill) { flg = TPHIP_FLAG_ZERO; done = true; }
+            if (fabs(g) < kFlatEps && fabs(h) < kFlatEps) { flg = TPHIP_FLAG_SATURATED; u = kUMax; }
+            else if (u >= kUMax && uphill) { flg = TPHIP_FLAG_SATURATED; }
+            else if (u <= kUMin && !uphill) { flg = TPHIP_FLAG_ZERO; }
             else {
                 if (uphill) { lo = u; lo_open = false; } else { hi = u; hi_open = false; }
                 double step = (h < 0.0) ? -g / h : (uphill ? kStepMax : -kStepMax);
@@ -280,19 +342,34 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
                 if (fabs(step) < kStepTol) {
                     f = fma(step, fma(0.5 * h, step, g), f);  // f + g*step + h*step^2/2
                     flg = TPHIP_FLAG_OK;
-                    done = true;
                 }
                 u = un;
+                if (flg < 0 && it >= kMaxIt) flg = TPHIP_FLAG_MAXIT;
+            }
+            if (flg >= 0) {  // this column is finished: write it out, the lane becomes free
+                const double r = exp(u) * kappa;
+                P.rate[col] = r;
+                P.subst[col] = r * P.chrono_length;
+                P.lnl[col] = f;
+                P.flag[col] = (uint8_t)flg;
+                done = true;
             }
         }
-    }
-    if (active) {
-        double s = exp(u);
-        double r = s * M->kappa;
-        P.rate[col] = r;
-        P.subst[col] = r * P.chrono_length;
-        P.lnl[col] = f;
-        P.flag[col] = flg;
+        // lane refill: free lanes take the next columns of the slice, in lane order
+        const unsigned long long free_mask = __ballot(done);
+        if (free_mask == 0ull) continue;
+        if (next < end) {
+            const int rank = __popcll(free_mask & ((1ull << lane) - 1ull));
+            const int idx = next + rank;
+            if (done && idx < end) {
+                col = work[idx];
+                u = 0.0; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; it = 0;
+                done = false;
+            }
+            next += __popcll(free_mask);
+        } else if (free_mask == ~0ull) {
+            break;  // slice exhausted and every lane finished
+        }
     }
     // evaluation count for the FLOP model (one atomic per wave)
     unsigned tot = evals;
@@ -303,6 +380,7 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
 
 // Diagnostic: evaluate f = log L, g = df/du, h = d2f/du2 at a caller-chosen u for EVERY column (no
 // classification, no optimiser).  Tests use it to check the derivative propagation by finite differences.
+// Uses the same chunk tables with chunk_cols columns per workgroup, 64 at a time.
 struct EvalParams {
     SiteParams S;
     const double* u;
@@ -314,28 +392,26 @@ struct EvalParams {
 __global__ __launch_bounds__(kSiteBlock) void eval_columns_kernel(EvalParams E) {
     extern __shared__ double lds[];
     double* wtab = lds;
-    double* stack = lds + 64;
+    double* mtab = lds + 64;
+    double* stack = lds + 96;
     const SiteParams& P = E.S;
     const int chunk = blockIdx.x;
     const int locus = P.chunk_locus[chunk];
-    const int cidx = P.chunk_index[chunk];
     const LocusModel* __restrict__ M = P.models + locus;
     const int lane = threadIdx.x;
-    {
-        int mask = lane >> 2, k = lane & 3;
-        double w = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w += ((mask >> j) & 1) ? M->Ui[k * 4 + j] : 0.0;
-        wtab[lane] = w;
-    }
-    __syncthreads();
+    build_tip_table(M, wtab, lane);
+    const ModelRegs R = load_model(M, mtab, lane);
     const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
-    const int64_t want = lo + (int64_t)cidx * kSiteBlock + lane;
-    const bool active = want < hi;
-    const int64_t col = active ? want : lo;
-    double f, g, h;
-    evaluate_column(P, M, wtab, stack, col, exp(E.u[col]), f, g, h);
-    if (active) { E.f[col] = f; E.g[col] = g; E.h[col] = h; }
+    const int64_t first = lo + (int64_t)P.chunk_index[chunk] * P.chunk_cols;
+    const int64_t last = (first + P.chunk_cols < hi) ? first + P.chunk_cols : hi;
+    for (int64_t base = first; base < last; base += kSiteBlock) {
+        const int64_t want = base + lane;
+        const bool active = want < last;
+        const int64_t col = active ? want : first;
+        double f, g, h;
+        evaluate_column(P, R, wtab, stack, col, exp(E.u[col]), f, g, h);
+        if (active) { E.f[col] = f; E.g[col] = g; E.h[col] = h; }
+    }
 }
 
 }  // namespace tphip

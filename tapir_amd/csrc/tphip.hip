@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -78,6 +79,7 @@ struct tphip_plan {
     TreeProgram prog;
     std::vector<int64_t> h_offsets;
     int64_t n_site_chunks = 0, n_pi_chunks = 0;
+    int32_t site_chunk_cols = kSiteBlock;  // columns per site_rate_kernel work slice (multiple of 64)
     DevBuf<TreeOp> d_ops;
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
@@ -154,16 +156,28 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->threshold = d->threshold; p->round_decimals = d->round_decimals; p->correction = d->correction;
     std::string terr = build_tree_program(d->ntaxa, d->nnodes, d->parent, d->branch_len, d->leaf_taxon, &p->prog);
     if (!terr.empty()) { delete p; return fail(TPHIP_ERR_INVALID, "tree: " + terr); }
-    const size_t lds_bytes = (64 + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    const size_t lds_bytes = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     if (lds_bytes > 160 * 1024) { delete p; return fail(TPHIP_ERR_INVALID, "tree needs a deeper LDS stack than 160 KiB allows"); }
     p->h_offsets.assign(d->locus_offsets, d->locus_offsets + d->nloci + 1);
 
-    // chunk tables: 64-column chunks for the optimiser, 1024-column chunks for classification and PI
+    // chunk tables: work slices for the optimiser, 1024-column chunks for classification and PI.
+    // A slice is what one wave works through with lane refill: long enough to amortise the drain at its end,
+    // short enough that the batch still makes >= ~4096 waves (16 per CU).
+    {
+        int64_t cc = (ncols / 4096 + kSiteBlock - 1) / kSiteBlock * kSiteBlock;
+        if (cc < kSiteBlock) cc = kSiteBlock;
+        if (cc > 1024) cc = 1024;
+        if (const char* e = getenv("TPHIP_SITE_CHUNK")) {  // tuning knob for experiments (multiple of 64)
+            long v = atol(e);
+            if (v >= kSiteBlock && v % kSiteBlock == 0) cc = v;
+        }
+        p->site_chunk_cols = (int32_t)cc;
+    }
     std::vector<int32_t> scl, sci, pcl, pci;
     std::vector<int64_t> lpo(d->nloci + 1, 0);
     for (int64_t l = 0; l < d->nloci; ++l) {
         const int64_t S = p->h_offsets[l + 1] - p->h_offsets[l];
-        for (int64_t c = 0; c * kSiteBlock < S; ++c) { scl.push_back((int32_t)l); sci.push_back((int32_t)c); }
+        for (int64_t c = 0; c * p->site_chunk_cols < S; ++c) { scl.push_back((int32_t)l); sci.push_back((int32_t)c); }
         for (int64_t c = 0; c * kPiChunk < S; ++c) { pcl.push_back((int32_t)l); pci.push_back((int32_t)c); }
         lpo[l + 1] = (int64_t)pcl.size();
     }
@@ -229,11 +243,12 @@ int tphip_plan_get_models(const tphip_plan* p, double* lam, double* U, double* U
     HIP_TRY(hipSetDevice(p->device));
     std::vector<LocusModel> h((size_t)p->nloci);
     HIP_TRY(hipMemcpy(h.data(), p->d_models.p, sizeof(LocusModel) * h.size(), hipMemcpyDeviceToHost));
-    for (int64_t l = 0; l < p->nloci; ++l) {
-        if (lam) memcpy(lam + 4 * l, h[l].lam, sizeof(double) * 4);
-        if (U) memcpy(U + 16 * l, h[l].U, sizeof(double) * 16);
-        if (Uinv) memcpy(Uinv + 16 * l, h[l].Ui, sizeof(double) * 16);
-        if (kappa) kappa[l] = h[l].kappa;
+    for (int64_t l = 0; l < p->nloci; ++l) {  // expand the packed device layout to full 4x4 matrices
+        const LocusModel& m = h[l];
+        if (lam) { lam[4 * l] = 0.0; for (int k = 1; k < 4; ++k) lam[4 * l + k] = m.lam[k - 1]; }
+        if (U) for (int i = 0; i < 4; ++i) { U[16 * l + 4 * i] = 1.0; for (int k = 1; k < 4; ++k) U[16 * l + 4 * i + k] = m.U[i * 3 + k - 1]; }
+        if (Uinv) for (int j = 0; j < 4; ++j) { Uinv[16 * l + j] = m.pi[j]; for (int k = 1; k < 4; ++k) Uinv[16 * l + 4 * k + j] = m.Ui[(k - 1) * 4 + j]; }
+        if (kappa) kappa[l] = m.kappa;
     }
     return TPHIP_OK;
 }
@@ -305,9 +320,10 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.states = d_states; S.ncols_total = p->ncols; S.models = p->d_models.p; S.ops = p->d_ops.p;
     S.nops = (int32_t)p->prog.ops.size(); S.stack_depth = p->prog.stack_depth; S.chrono_length = p->prog.chrono_length;
     S.locus_offsets = p->d_offsets.p; S.chunk_locus = p->d_site_chunk_locus.p; S.chunk_index = p->d_site_chunk_index.p;
+    S.chunk_cols = p->site_chunk_cols;
     S.work_cols = work_cols; S.work_count = work_count;
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
-    const size_t lds = (64 + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_site_chunks > 0)
@@ -552,10 +568,11 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     E.S.states = d_s; E.S.ncols_total = p->ncols; E.S.models = p->d_models.p; E.S.ops = p->d_ops.p;
     E.S.nops = (int32_t)p->prog.ops.size(); E.S.stack_depth = p->prog.stack_depth; E.S.chrono_length = p->prog.chrono_length;
     E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
+    E.S.chunk_cols = p->site_chunk_cols;
     E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
     E.S.flag = nullptr; E.S.eval_counter = nullptr;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
-    const size_t lds = (64 + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     if (p->n_site_chunks > 0) eval_columns_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds>>>(E);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
