@@ -38,7 +38,11 @@ constexpr double kStepTol = 1e-9;
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
 constexpr int kSiteBlock = 64;      // one wavefront per workgroup
-constexpr int kSiteLdsHeader = 96;  // doubles of LDS before the stack: tip table [16][4] + model [32]
+constexpr int kSiteLdsHeader = 160;  // doubles of LDS before the stack: tip table [16][4] + model [32] + 2^(j/64) [64]
+#ifndef TPHIP_EXP_TABLE
+#define TPHIP_EXP_TABLE 1
+#endif
+constexpr bool kUseExpTable = TPHIP_EXP_TABLE != 0;
 
 struct SiteParams {
     const uint8_t* states;       // [ntaxa][ncols_total]
@@ -65,14 +69,20 @@ struct Partial {  // value and first/second derivative (wrt u) of the 4 conditio
     double v[4], d1[4], d2[4];
 };
 
-// exp(x) for x <= 0 (branch exponents lam*t*s are never positive).  Cody-Waite reduction + degree-13
-// Taylor polynomial on |r| <= ln2/2 (truncation < 4e-18); 2^n applied through the exponent field.
-// Error vs libm <= 1 ulp on [-708, 0]; results below 2^-1021 flush to 0.
+// exp(x) for x <= 0 (branch exponents lam*t*s are never positive).
+//   n = round(x*log2 e) by the 1.5*2^52 shift trick (one FMA leaves n in the low mantissa bits, one ADD gives it
+//   back as a double: no v_rndne / v_cvt), Cody-Waite reduction r = x - n ln2 (two FMAs), degree-13 Taylor
+//   polynomial on |r| <= ln2/2 (truncation < 4e-18), 2^n applied by adding n to the exponent field.
+// x is clamped at -708 (exp(-708) = 3e-308 is the smallest normal result; anything smaller contributes nothing
+// to a likelihood here).  Error vs libm <= 1 ulp on [-708, 0].
 __device__ __forceinline__ double exp_nonpos(double x) {
     const double LOG2E = 1.4426950408889634074;
     const double LN2_HI = 6.93147180369123816490e-01;
     const double LN2_LO = 1.90821492927058770002e-10;
-    double n = rint(x * LOG2E);
+    const double SHIFT = 6755399441055744.0;  // 1.5 * 2^52
+    x = fmax(x, -708.0);
+    const double t = fma(x, LOG2E, SHIFT);    // low 32 bits of t = n (two's complement)
+    const double n = t - SHIFT;
     double r = fma(-n, LN2_HI, x);
     r = fma(-n, LN2_LO, r);
     double p = 1.6059043836821613e-10;          // 1/13!
@@ -89,10 +99,54 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    int ni = (int)n;
-    // multiply by 2^ni through the exponent bits (p in [0.70, 1.42], result stays normal for ni >= -1021)
-    long long bits = __double_as_longlong(p) + (long long)((unsigned long long)(long long)ni << 52);
-    return (ni < -1021) ? 0.0 : __longlong_as_double(bits);
+    // p in [0.70, 1.42]; n >= -1021 after the clamp, so adding n to the exponent field keeps the result normal
+    const int ni = (int)(unsigned)__double_as_longlong(t);
+    const int hi = __double2hiint(p) + (int)((unsigned)ni << 20);
+    return __hiloint2double(hi, __double2loint(p));
+}
+
+// 2^(j/64), j = 0..63, correctly rounded; copied into LDS per workgroup for exp_nonpos_tab.
+__device__ __constant__ const double kExp2Table[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951};
+
+// Table-driven exp(x), x <= 0 (Tang 1989 with a 64-entry table): x = (64 n + j) ln2/64 + r, |r| <= ln2/128,
+// exp(x) = 2^n * T[j] * (1 + q(r)), q of degree 5 (truncation r^6/720 < 4e-17).  11 FP64 ops + one LDS read
+// instead of 19 FP64 ops; error <= 1.5 ulp.
+__device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ etab) {
+    const double INV = 92.33248261689366;           // 64 / ln2
+    const double L_HI = 0.01083042469326756;        // ln2/64, 32 significant bits: k*L_HI is exact for |k| < 2^20
+    const double L_LO = 2.9815858269852933e-12;
+    const double SHIFT = 6755399441055744.0;        // 1.5 * 2^52
+    x = fmax(x, -708.0);
+    const double t = fma(x, INV, SHIFT);            // low 32 bits of t = k = 64 n + j
+    const double kd = t - SHIFT;
+    double r = fma(-kd, L_HI, x);
+    r = fma(-kd, L_LO, r);
+    const int k = (int)(unsigned)__double_as_longlong(t);
+    const double T = etab[k & 63];
+    double q = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
+    q = fma(q, r, 1.6666666666666666e-01);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = q * r;                                      // q = exp(r) - 1
+    const double p = fma(T, q, T);                  // in [0.99, 2.0)
+    const int hi = __double2hiint(p) + (int)((unsigned)(k >> 6) << 20);
+    return __hiloint2double(hi, __double2loint(p));
 }
 
 // acc *= m (product rule for value / first / second derivative)
@@ -130,12 +184,12 @@ __device__ __forceinline__ ModelRegs load_model(const LocusModel* __restrict__ M
 
 // message of a tip through its branch: P(t s) * tip, with derivatives wrt u = log s.
 // w[k] = (U^-1 tip)_k from the LDS mask table; x_k = lam_k t s; e_k = exp(x_k).
-__device__ __forceinline__ void tip_message(const ModelRegs& R, const double* w, double ts, Partial& m) {
+__device__ __forceinline__ void tip_message(const ModelRegs& R, const double* __restrict__ etab, const double* w, double ts, Partial& m) {
     double a[3], b[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         double x = R.lam[k] * ts;
-        double e = exp_nonpos(x);
+        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
         a[k] = e * w[k + 1];
         b[k] = x * a[k];
         c[k] = fma(x, b[k], b[k]);
@@ -150,7 +204,7 @@ __device__ __forceinline__ void tip_message(const ModelRegs& R, const double* w,
 }
 
 // acc <- P(t s) * acc with derivatives (internal branch)
-__device__ __forceinline__ void branch_apply(const ModelRegs& R, double ts, Partial& p) {
+__device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* __restrict__ etab, double ts, Partial& p) {
     double w0[4], w1[4], w2[4];
     w0[0] = fma(R.pi[3], p.v[3], fma(R.pi[2], p.v[2], fma(R.pi[1], p.v[1], R.pi[0] * p.v[0])));
     w1[0] = fma(R.pi[3], p.d1[3], fma(R.pi[2], p.d1[2], fma(R.pi[1], p.d1[1], R.pi[0] * p.d1[0])));
@@ -166,7 +220,7 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, double ts, Part
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         double x = R.lam[k] * ts;
-        double e = exp_nonpos(x);
+        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
         a[k] = e * w0[k + 1];
         double ew1 = e * w1[k + 1], ew2 = e * w2[k + 1];
         b[k] = fma(x, a[k], ew1);
@@ -182,11 +236,16 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, double ts, Part
 }
 
 // Rescale when the partial gets small (deep trees / hundreds of taxa); exponent goes to `scale`.
+// Partials are non-negative, so their high words order like unsigned integers: the test is two integer max3
+// and one compare instead of three FP64 max and an exponent extraction.
 __device__ __forceinline__ void partial_rescale(Partial& p, int& scale) {
-    double mx = fmax(fmax(p.v[0], p.v[1]), fmax(p.v[2], p.v[3]));
-    int e = (int)((__double_as_longlong(mx) >> 52) & 0x7ff) - 1023;
-    if (mx > 0.0 && e < -256) {
-        double f = __longlong_as_double((long long)(1023 - e) << 52);  // 2^-e
+    const unsigned h0 = (unsigned)__double2hiint(p.v[0]), h1 = (unsigned)__double2hiint(p.v[1]);
+    const unsigned h2 = (unsigned)__double2hiint(p.v[2]), h3 = (unsigned)__double2hiint(p.v[3]);
+    const unsigned mx = max(max(h0, h1), max(h2, h3));
+    const unsigned kLow = (unsigned)(1023 - 256) << 20;  // 2^-256
+    if (mx < kLow && mx >= (1u << 20)) {                 // below 2^-256 and still a normal number
+        const int e = (int)(mx >> 20) - 1023;
+        const double f = __hiloint2double((1023 - e) << 20, 0);  // 2^-e
 #pragma unroll
         for (int i = 0; i < 4; ++i) { p.v[i] *= f; p.d1[i] *= f; p.d2[i] *= f; }
         scale += e;
@@ -199,7 +258,7 @@ __device__ __forceinline__ unsigned load_state(const SiteParams& P, int taxon, i
 
 // One likelihood evaluation for this lane's column: f = log L, g = df/du, h = d2f/du2 at s = exp(u).
 __device__ __forceinline__ void evaluate_column(const SiteParams& P, const ModelRegs& R, const double* __restrict__ wtab,
-                                                double* __restrict__ stack, int64_t col, double s, double& f,
+                                                const double* __restrict__ etab, double* __restrict__ stack, int64_t col, double s, double& f,
                                                 double& g, double& h) {
     Partial acc;
     int scale = 0;
@@ -242,13 +301,13 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
                 mask = mask ? mask : 15u;
                 const double* w = wtab + mask * 4;
                 const double wv[4] = {w[0], w[1], w[2], w[3]};
-                tip_message(R, wv, op.t * s, m);
+                tip_message(R, etab, wv, op.t * s, m);
             }
             partial_rescale(acc, scale);
             partial_mul(acc, m);
         } else if (op.code == OP_BRANCH) {
             partial_rescale(acc, scale);
-            branch_apply(R, op.t * s, acc);
+            branch_apply(R, etab, op.t * s, acc);
         } else {  // OP_PUSH: park the finished sibling, start the next subtree from the identity
             double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
 #pragma unroll
@@ -293,7 +352,9 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
     extern __shared__ double lds[];
     double* wtab = lds;          // [16 masks][4]
     double* mtab = lds + 64;     // [32] the locus' model
-    double* stack = lds + 96;    // [stack_depth][12][64]
+    double* etab = lds + 96;     // [64] 2^(j/64)
+    double* stack = lds + kSiteLdsHeader;  // [stack_depth][12][64]
+    etab[threadIdx.x] = kExp2Table[threadIdx.x];
     const int chunk = blockIdx.x;
     const int locus = P.chunk_locus[chunk];
     const int count = P.work_count[locus];
@@ -316,7 +377,7 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
     unsigned evals = 0;
     while (true) {
         double f, g, h;
-        evaluate_column(P, R, wtab, stack, col, exp(u), f, g, h);
+        evaluate_column(P, R, wtab, etab, stack, col, exp(u), f, g, h);
         if (!done) {
             ++evals;
             ++it;
@@ -393,7 +454,9 @@ __global__ __launch_bounds__(kSiteBlock) void eval_columns_kernel(EvalParams E) 
     extern __shared__ double lds[];
     double* wtab = lds;
     double* mtab = lds + 64;
-    double* stack = lds + 96;
+    double* etab = lds + 96;
+    double* stack = lds + kSiteLdsHeader;
+    etab[threadIdx.x] = kExp2Table[threadIdx.x];
     const SiteParams& P = E.S;
     const int chunk = blockIdx.x;
     const int locus = P.chunk_locus[chunk];
@@ -409,7 +472,7 @@ __global__ __launch_bounds__(kSiteBlock) void eval_columns_kernel(EvalParams E) 
         const bool active = want < last;
         const int64_t col = active ? want : first;
         double f, g, h;
-        evaluate_column(P, R, wtab, stack, col, exp(E.u[col]), f, g, h);
+        evaluate_column(P, R, wtab, etab, stack, col, exp(E.u[col]), f, g, h);
         if (active) { E.f[col] = f; E.g[col] = g; E.h[col] = h; }
     }
 }

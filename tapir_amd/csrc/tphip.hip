@@ -162,11 +162,11 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
 
     // chunk tables: work slices for the optimiser, 1024-column chunks for classification and PI.
     // A slice is what one wave works through with lane refill: long enough to amortise the drain at its end,
-    // short enough that the batch still makes >= ~4096 waves (16 per CU).
+    // short enough that the batch still makes >= ~8192 waves (32 per CU).
     {
-        int64_t cc = (ncols / 4096 + kSiteBlock - 1) / kSiteBlock * kSiteBlock;
+        int64_t cc = (ncols / 8192 + kSiteBlock - 1) / kSiteBlock * kSiteBlock;
         if (cc < kSiteBlock) cc = kSiteBlock;
-        if (cc > 1024) cc = 1024;
+        if (cc > 512) cc = 512;  // measured on C3: 512 beats 256 and 1024 (drain of the last slices vs refill gain)
         if (const char* e = getenv("TPHIP_SITE_CHUNK")) {  // tuning knob for experiments (multiple of 64)
             long v = atol(e);
             if (v >= kSiteBlock && v % kSiteBlock == 0) cc = v;
