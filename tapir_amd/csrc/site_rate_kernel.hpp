@@ -55,7 +55,7 @@ struct SiteParams {
     const int64_t* locus_offsets;  // [nloci+1]
     const int32_t* chunk_locus;    // [nchunks]  work slices of chunk_cols columns, never straddling loci
     const int32_t* chunk_index;    // [nchunks]  index of the slice inside its locus
-    int32_t chunk_cols;            // columns per slice (multiple of 64)
+    int32_t chunk_cols;            // target columns per slice
     const int32_t* work_cols;      // [ncols_total] compacted column ids, per locus at locus_offsets[l]
     const int32_t* work_count;     // [nloci]
     double* rate;
@@ -357,10 +357,17 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
     etab[threadIdx.x] = kExp2Table[threadIdx.x];
     const int chunk = blockIdx.x;
     const int locus = P.chunk_locus[chunk];
+    // The locus' `count` columns that need the optimiser are split into `ns` EQUAL slices of about chunk_cols
+    // columns (a short remainder slice would spend most of its life draining at low lane occupancy); the grid
+    // was sized for the worst case (every column needs the optimiser), surplus workgroups leave at once.
     const int count = P.work_count[locus];
-    const int begin = P.chunk_index[chunk] * P.chunk_cols;
-    if (begin >= count) return;  // every column of this slice was answered by classify_kernel
-    const int end = min(count, begin + P.chunk_cols);
+    if (count == 0) return;
+    int ns = (count + P.chunk_cols / 2) / P.chunk_cols;
+    ns = ns < 1 ? 1 : ns;
+    const int j = P.chunk_index[chunk];
+    if (j >= ns) return;
+    const int begin = (int)((long long)j * count / ns);
+    const int end = (int)((long long)(j + 1) * count / ns);
     const LocusModel* __restrict__ M = P.models + locus;
     const int lane = threadIdx.x;
     build_tip_table(M, wtab, lane);
@@ -465,8 +472,12 @@ __global__ __launch_bounds__(kSiteBlock) void eval_columns_kernel(EvalParams E) 
     build_tip_table(M, wtab, lane);
     const ModelRegs R = load_model(M, mtab, lane);
     const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
-    const int64_t first = lo + (int64_t)P.chunk_index[chunk] * P.chunk_cols;
-    const int64_t last = (first + P.chunk_cols < hi) ? first + P.chunk_cols : hi;
+    const int64_t S = hi - lo;
+    int64_t ns = (S + P.chunk_cols / 2) / P.chunk_cols;  // = workgroups launched for this locus
+    ns = ns < 1 ? 1 : ns;
+    const int64_t j = P.chunk_index[chunk];
+    const int64_t first = lo + j * S / ns;
+    const int64_t last = lo + (j + 1) * S / ns;
     for (int64_t base = first; base < last; base += kSiteBlock) {
         const int64_t want = base + lane;
         const bool active = want < last;

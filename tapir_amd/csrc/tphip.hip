@@ -2,6 +2,7 @@
 // one-off tree compilation, table uploads and kernel launches; there is no CPU compute path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -164,12 +165,15 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     // A slice is what one wave works through with lane refill: long enough to amortise the drain at its end,
     // short enough that the batch still makes >= ~8192 waves (32 per CU).
     {
-        int64_t cc = (ncols / 8192 + kSiteBlock - 1) / kSiteBlock * kSiteBlock;
-        if (cc < kSiteBlock) cc = kSiteBlock;
-        if (cc > 512) cc = 512;  // measured on C3: 512 beats 256 and 1024 (drain of the last slices vs refill gain)
-        if (const char* e = getenv("TPHIP_SITE_CHUNK")) {  // tuning knob for experiments (multiple of 64)
+        // Target slice length.  Measured on the C2/C3/C4 shapes: the drain at the end of a
+        // slice favours long slices (a 780-column locus cut in two costs +32 %), while a batch of few huge loci
+        // (C3) still needs several thousand waves to balance the last round of the grid.
+        int64_t cc = ncols / 8192;
+        if (cc < 512) cc = 512;
+        if (cc > 1024) cc = 1024;
+        if (const char* e = getenv("TPHIP_SITE_CHUNK")) {  // tuning knob for experiments
             long v = atol(e);
-            if (v >= kSiteBlock && v % kSiteBlock == 0) cc = v;
+            if (v >= kSiteBlock) cc = v;
         }
         p->site_chunk_cols = (int32_t)cc;
     }
@@ -177,7 +181,8 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     std::vector<int64_t> lpo(d->nloci + 1, 0);
     for (int64_t l = 0; l < d->nloci; ++l) {
         const int64_t S = p->h_offsets[l + 1] - p->h_offsets[l];
-        for (int64_t c = 0; c * p->site_chunk_cols < S; ++c) { scl.push_back((int32_t)l); sci.push_back((int32_t)c); }
+        const int64_t ns_max = std::max<int64_t>(1, (S + p->site_chunk_cols / 2) / p->site_chunk_cols);
+        for (int64_t c = 0; c < ns_max && S > 0; ++c) { scl.push_back((int32_t)l); sci.push_back((int32_t)c); }
         for (int64_t c = 0; c * kPiChunk < S; ++c) { pcl.push_back((int32_t)l); pci.push_back((int32_t)c); }
         lpo[l + 1] = (int64_t)pcl.size();
     }
