@@ -32,12 +32,12 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
 def flops_per_eval(oc):
     """FP64 flop count of one likelihood evaluation (value + 1st + 2nd u-derivative), from the op mix of the
     compiled tree program and the arithmetic each op issues in site_rate_kernel.hpp (FMA = 2 flop):
-      exp_nonpos                      32  (mul, rint, 15 fma)
-      tip message                    176  (3 exp + 15 + 64 + 1)
-      internal branch                283  (84 for U^-1 v/v'/v'', 3 exp + 30, 72 for U, 1)
-      product rule (TIP_MUL/POP_MUL)  40
+      exp_nonpos_tab                  19  (max, fma, add, 2 fma, 4 fma + mul, fma)
+      tip message                    137  (3 exp + 15 + 64 + 1)
+      internal branch                244  (84 for U^-1 v/v'/v'', 3 exp + 30, 72 for U, 1)
+      product rule (TIP_*/POP_MUL)    40
       root: L, L', L'' + log, div   ~ 50"""
-    return ((oc["tip_set"] + oc["tip_mul"]) * 176 + (oc["tip_mul"] + oc["pop_mul"]) * 40 + oc["branch"] * 283 + 50)
+    return ((oc["tip_set"] + oc["tip_mul"]) * (137 + 40) + oc["pop_mul"] * 40 + oc["branch"] * 244 + 50)
 
 
 def main():
