@@ -17,12 +17,18 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
   timeout -k 10 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
-import csv, glob, collections
-tot = collections.defaultdict(float); n = collections.defaultdict(int)
+import csv, glob, collections, json
+tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "site_rate_kernel" in r["Kernel_Name"]:
-            tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-for k in sorted(tot): print(k, tot[k] / max(1, n[k]), "(avg over", n[k], "dispatches)")
+        kn = r["Kernel_Name"]
+        if "tphip::" in kn:
+            k = kn.split("tphip::")[1].split("(")[0]
+            tot[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
+out = {k: {c: tot[k][c] / max(1, n[k][c]) for c in sorted(tot[k])} for k in tot}
+json.dump(out, open("$OUT/summary.json", "w"), indent=1)
+for c in sorted(out.get("site_rate_kernel", {})): print(c, out["site_rate_kernel"][c])
+for k in out:
+    print(k, "FETCH_SIZE", out[k].get("FETCH_SIZE"), "WRITE_SIZE", out[k].get("WRITE_SIZE"))
 PY
 rm -rf $OUT/p[0-9]*
