@@ -38,6 +38,8 @@ struct ClassifyParams {
     uint8_t* flag;
     int32_t* nres;
     double chrono_length;
+    const int32_t* tip_taxon;     // [ntaxa] alignment row of the k-th tip op of the tree program
+    uint32_t* packed;             // [ceil(ntaxa/8)][ncols_total] out: 8 four-bit masks per word, program tip order
 };
 
 // One thread per column; a wave reads 64 consecutive bytes of each taxon row.
@@ -50,16 +52,23 @@ __global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
     for (int j = 0; j < kPiColsPerThread; ++j) {
         const int64_t col = base + j * kPiBlock + threadIdx.x;
         if (col >= hi) continue;
-        unsigned uni = 0;
+        unsigned uni = 0, word = 0;
         int resolved = 0, informative = 0;
         const uint8_t* p = P.states + col;
-        for (int t = 0; t < P.ntaxa; ++t) {
+        for (int k = 0; k < P.ntaxa; ++k) {
+            const int t = P.tip_taxon[k];  // uniform -> scalar load; visiting tips in program order lets the same
+                                           // pass emit the packed words site_rate_kernel keeps in registers
             unsigned m = p[(int64_t)t * P.ncols_total] & 15u;
             m = m ? m : 15u;
             const bool res = (m != 15u);
             uni |= res ? m : 0u;
             resolved += res;
             informative += (__popc(m) == 1);
+            word |= m << (4 * (k & 7));
+            if ((k & 7) == 7 || k == P.ntaxa - 1) {
+                P.packed[(int64_t)(k >> 3) * P.ncols_total + col] = word;
+                word = 0;
+            }
         }
         P.nres[col] = informative;
         uint8_t flg = TPHIP_FLAG_OK;  // provisional: site_rate_kernel will overwrite

@@ -56,8 +56,13 @@ struct SiteParams {
     const int32_t* chunk_locus;    // [nchunks]  work slices of chunk_cols columns, never straddling loci
     const int32_t* chunk_index;    // [nchunks]  index of the slice inside its locus
     int32_t chunk_cols;            // target columns per slice
+    const uint32_t* packed;        // [nwords][ncols_total] 8 tip masks per word, tips in program order (classify_kernel)
+    int32_t nwords;                // ceil(ntips / 8)
     const int32_t* work_cols;      // [ncols_total] compacted column ids, per locus at locus_offsets[l]
     const int32_t* work_count;     // [nloci]
+    const int64_t* work_prefix;    // [nloci+1] exclusive scan of work_count (scan_counts_kernel)
+    int64_t nloci;
+    int32_t persistent;            // 1: grid = resident waves, equal shares of the global work list; 0: grid = slices
     double* rate;
     double* subst;
     double* lnl;
@@ -256,13 +261,57 @@ __device__ __forceinline__ unsigned load_state(const SiteParams& P, int taxon, i
     return P.states[(int64_t)taxon * P.ncols_total + col];
 }
 
+// Word `w` (wave-uniform index) of the lane's packed tip states.  The index is scalar, so this is a chain of
+// scalar compares feeding v_cndmask -- executed once per 8 tips.
+// `pk[i]` for a compile-time i, through an opaque copy: keeps the words in VGPRs (without it the selection below
+// is rewritten as a dynamically indexed scratch array).
+template <int NW>
+__device__ __forceinline__ uint32_t word_at(const uint32_t (&pk)[NW > 0 ? NW : 1], int i) {
+    uint32_t v = pk[i];
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// Word `w` (wave-uniform index) of the lane's packed tip states; executed once per 8 tips.  Up to 8 words: a
+// chain of scalar compares feeding v_cndmask.  More words: scalar branches on the high bits select a group
+// of 8 first, so the cost stays ~8 selects instead of NW.
+template <int NW>
+__device__ __forceinline__ uint32_t pick_word(const uint32_t (&pk)[NW > 0 ? NW : 1], int w) {
+    if constexpr (NW <= 8) {
+        uint32_t r = word_at<NW>(pk, 0);
+#pragma unroll
+        for (int i = 1; i < NW; ++i) { const uint32_t c = word_at<NW>(pk, i); r = (w == i) ? c : r; }
+        return r;
+    } else {
+        const int grp = __builtin_amdgcn_readfirstlane(w >> 3), sub = w & 7;
+        uint32_t r = 0;
+#pragma unroll
+        for (int g = 0; g < NW / 8; ++g) {
+            if (grp == g) {  // wave-uniform: a scalar branch
+                r = word_at<NW>(pk, 8 * g);
+#pragma unroll
+                for (int i = 1; i < 8; ++i) { const uint32_t c = word_at<NW>(pk, 8 * g + i); r = (sub == i) ? c : r; }
+            }
+        }
+        return r;
+    }
+}
+
 // One likelihood evaluation for this lane's column: f = log L, g = df/du, h = d2f/du2 at s = exp(u).
+// NW > 0: the column's tip states live in registers (pk: 8 four-bit masks per word, in program tip order), so
+//         the Newton iterations never touch the alignment again;
+// NW = 0: states are fetched from the byte array one op ahead (trees with more than 256 tips, and the
+//         eval_columns diagnostic, which thereby cross-checks the packed path).
+template <int NW>
 __device__ __forceinline__ void evaluate_column(const SiteParams& P, const ModelRegs& R, const double* __restrict__ wtab,
-                                                const double* __restrict__ etab, double* __restrict__ stack, int64_t col, double s, double& f,
+                                                const double* __restrict__ etab, double* __restrict__ stack, int64_t col,
+                                                const uint32_t (&pk)[NW > 0 ? NW : 1], double s, double& f,
                                                 double& g, double& h) {
     Partial acc;
     int scale = 0;
     int sp = 0;
+    int tk = 0;          // tips consumed so far (wave-uniform)
+    uint32_t cur = 0;    // current packed word, already shifted
     const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc.v[i] = 1.0; acc.d1[i] = 0.0; acc.d2[i] = 0.0; }
@@ -274,14 +323,17 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
     TreeOp op, nxt;
     op.code = ops[0].code; op.taxon = ops[0].taxon; op.t = ops[0].t;
     { const int i1 = last < 1 ? last : 1; nxt.code = ops[i1].code; nxt.taxon = ops[i1].taxon; nxt.t = ops[i1].t; }
-    unsigned st = load_state(P, op.taxon, col);  // the program always starts at a tip
+    unsigned st = 15u;
+    if constexpr (NW == 0) st = load_state(P, op.taxon, col);  // the program always starts at a tip
     for (int ip = 0; ip < P.nops; ++ip) {
-        // Two-deep fetch pipeline: op ip+2 (scalar load) and the state byte of op ip+1 (global byte load) are
-        // issued here and consumed one iteration later, i.e. they stay in flight under this op's FP64 work.
+        // Two-deep fetch pipeline: op ip+2 (scalar load) and, on the byte path, the state of op ip+1 are issued
+        // here and consumed one iteration later, i.e. they stay in flight under this op's FP64 work.
         TreeOp nn;
         { const int i2 = (ip + 2 < last) ? ip + 2 : last; nn.code = ops[i2].code; nn.taxon = ops[i2].taxon; nn.t = ops[i2].t; }
         unsigned st_nxt = 15u;
-        if (nxt.code <= OP_TIP_MUL) st_nxt = load_state(P, nxt.taxon, col);
+        if constexpr (NW == 0) {
+            if (nxt.code <= OP_TIP_MUL) st_nxt = load_state(P, nxt.taxon, col);
+        }
         if (op.code != OP_BRANCH && op.code != OP_PUSH) {
             // acc *= m, with m the message of a tip (TIP_SET / TIP_MUL) or a parked sibling (POP_MUL).
             // TIP_SET is TIP_MUL onto the identity: acc is the identity at program start and after every PUSH,
@@ -297,8 +349,16 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
                     m.d2[i] = slot[(8 + i) * kSiteBlock];
                 }
             } else {
-                unsigned mask = st & 15u;
-                mask = mask ? mask : 15u;
+                unsigned mask;
+                if constexpr (NW > 0) {
+                    if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
+                    mask = cur & 15u;   // zero codes were turned into 15 when the word was packed
+                    cur >>= 4;
+                    ++tk;
+                } else {
+                    mask = st & 15u;
+                    mask = mask ? mask : 15u;
+                }
                 const double* w = wtab + mask * 4;
                 const double wv[4] = {w[0], w[1], w[2], w[3]};
                 tip_message(R, etab, wv, op.t * s, m);
@@ -348,95 +408,154 @@ __device__ __forceinline__ void build_tip_table(const LocusModel* __restrict__ M
     wtab[lane] = w;
 }
 
+// Exclusive scan of the per-locus work counts (one workgroup; L is at most a few 10^4).
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* __restrict__ count, int64_t nloci,
+                                                           int64_t* __restrict__ prefix) {
+    __shared__ long long part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (nloci + 1023) / 1024;
+    const int64_t lo = t * per, hi = (lo + per < nloci) ? lo + per : nloci;
+    long long s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += count[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+        prefix[nloci] = run;
+    }
+    __syncthreads();
+    long long run = part[t];
+    for (int64_t i = lo; i < hi; ++i) { prefix[i] = run; run += count[i]; }
+}
+
+// Persistent, statically balanced launch: the grid is exactly the number of waves the chip keeps resident;
+// wave w takes the w-th EQUAL share of the batch's global work list (the concatenation of every locus'
+// compacted column list, located through the prefix sums of the per-locus counts).  Inside one locus segment
+// the wave refills freed lanes continuously; it drains only at a locus boundary (the model changes) and at the
+// end of its share.  Equal column counts balance the waves to ~2 % (thousands of columns per wave), so there
+// is neither a partially filled last round of workgroups nor a tail of short slices.  No wave waits on
+// another: every wave leaves after its own share, whatever the others do.
+template <int NW>
 __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
     extern __shared__ double lds[];
     double* wtab = lds;          // [16 masks][4]
     double* mtab = lds + 64;     // [32] the locus' model
     double* etab = lds + 96;     // [64] 2^(j/64)
     double* stack = lds + kSiteLdsHeader;  // [stack_depth][12][64]
-    etab[threadIdx.x] = kExp2Table[threadIdx.x];
-    const int chunk = blockIdx.x;
-    const int locus = P.chunk_locus[chunk];
-    // The locus' `count` columns that need the optimiser are split into `ns` EQUAL slices of about chunk_cols
-    // columns (a short remainder slice would spend most of its life draining at low lane occupancy); the grid
-    // was sized for the worst case (every column needs the optimiser), surplus workgroups leave at once.
-    const int count = P.work_count[locus];
-    if (count == 0) return;
-    int ns = (count + P.chunk_cols / 2) / P.chunk_cols;
-    ns = ns < 1 ? 1 : ns;
-    const int j = P.chunk_index[chunk];
-    if (j >= ns) return;
-    const int begin = (int)((long long)j * count / ns);
-    const int end = (int)((long long)(j + 1) * count / ns);
-    const LocusModel* __restrict__ M = P.models + locus;
     const int lane = threadIdx.x;
-    build_tip_table(M, wtab, lane);
-    const ModelRegs R = load_model(M, mtab, lane);
-    const double kappa = mtab[31];
-    const int32_t* __restrict__ work = P.work_cols + P.locus_offsets[locus];
-
-    int next = begin + kSiteBlock;  // wave-uniform: first work index not yet handed to a lane
-    bool done = (begin + lane >= end);
-    int64_t col = work[done ? begin : begin + lane];
-    double u = 0.0, lo = kUMin, hi = kUMax;
-    bool lo_open = true, hi_open = true;
-    int it = 0;
-    unsigned evals = 0;
-    while (true) {
-        double f, g, h;
-        evaluate_column(P, R, wtab, etab, stack, col, exp(u), f, g, h);
-        if (!done) {
-            ++evals;
-            ++it;
-            int flg = -1;
-            const bool uphill = !(g <= 0.0);
-            // Saturation: beyond this point g is second-order small under first-order rounding noise, its
-            // sign is meaningless; report the policy value s = 1e4 (same rule as the oracle).
-            if (fabs(g) < kFlatEps && fabs(h) < kFlatEps) { flg = TPHIP_FLAG_SATURATED; u = kUMax; }
-            else if (u >= kUMax && uphill) { flg = TPHIP_FLAG_SATURATED; }
-            else if (u <= kUMin && !uphill) { flg = TPHIP_FLAG_ZERO; }
-            else {
-                if (uphill) { lo = u; lo_open = false; } else { hi = u; hi_open = false; }
-                double step = (h < 0.0) ? -g / h : (uphill ? kStepMax : -kStepMax);
-                if (!(step <= kStepMax)) step = kStepMax;
-                if (step < -kStepMax) step = -kStepMax;
-                double un = u + step;
-                // the bracket safeguard must not see a converged (possibly underflowing) Newton step
-                if (fabs(step) >= kStepTol) {
-                    if (un >= hi) un = hi_open ? kUMax : 0.5 * (lo + hi);
-                    else if (un <= lo) un = lo_open ? kUMin : 0.5 * (lo + hi);
-                    step = un - u;
-                }
-                if (fabs(step) < kStepTol) {
-                    f = fma(step, fma(0.5 * h, step, g), f);  // f + g*step + h*step^2/2
-                    flg = TPHIP_FLAG_OK;
-                }
-                u = un;
-                if (flg < 0 && it >= kMaxIt) flg = TPHIP_FLAG_MAXIT;
-            }
-            if (flg >= 0) {  // this column is finished: write it out, the lane becomes free
-                const double r = exp(u) * kappa;
-                P.rate[col] = r;
-                P.subst[col] = r * P.chrono_length;
-                P.lnl[col] = f;
-                P.flag[col] = (uint8_t)flg;
-                done = true;
-            }
+    etab[lane] = kExp2Table[lane];
+    int64_t g0, g1, lo_l;
+    if (P.persistent) {
+        const int64_t total = P.work_prefix[P.nloci];
+        g0 = (int64_t)blockIdx.x * total / gridDim.x;
+        g1 = (int64_t)(blockIdx.x + 1) * total / gridDim.x;
+        if (g0 >= g1) return;
+        // first locus of this share: the last l with prefix[l] <= g0 (binary search, wave-uniform)
+        int64_t hi_l = P.nloci;
+        lo_l = 0;
+        while (hi_l - lo_l > 1) {
+            const int64_t mid = (lo_l + hi_l) >> 1;
+            if (P.work_prefix[mid] <= g0) lo_l = mid; else hi_l = mid;
         }
-        // lane refill: free lanes take the next columns of the slice, in lane order
-        const unsigned long long free_mask = __ballot(done);
-        if (free_mask == 0ull) continue;
-        if (next < end) {
-            const int rank = __popcll(free_mask & ((1ull << lane) - 1ull));
-            const int idx = next + rank;
-            if (done && idx < end) {
-                col = work[idx];
-                u = 0.0; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; it = 0;
-                done = false;
+    } else {
+        // Small batches (a share would be a few hundred columns): one workgroup per locus-aligned slice instead,
+        // because cutting a small locus in two doubles its prologue and drain.  The locus' `count` columns are
+        // split into `ns` EQUAL slices of about chunk_cols; the grid was sized for the worst case (every column
+        // needs the optimiser) and surplus workgroups leave at once.
+        lo_l = P.chunk_locus[blockIdx.x];
+        const int count = P.work_count[lo_l];
+        if (count == 0) return;
+        int ns = (count + P.chunk_cols / 2) / P.chunk_cols;
+        ns = ns < 1 ? 1 : ns;
+        const int j = P.chunk_index[blockIdx.x];
+        if (j >= ns) return;
+        const int64_t pbeg = P.work_prefix[lo_l];
+        g0 = pbeg + (int64_t)j * count / ns;
+        g1 = pbeg + (int64_t)(j + 1) * count / ns;
+    }
+    unsigned evals = 0;
+    int64_t gpos = g0;
+    for (int64_t locus = lo_l; gpos < g1; ++locus) {
+        const int64_t pbeg = P.work_prefix[locus], pend = P.work_prefix[locus + 1];
+        const int64_t seg_end = pend < g1 ? pend : g1;
+        if (seg_end <= gpos) continue;  // locus without optimiser work
+        const int begin = (int)(gpos - pbeg), end = (int)(seg_end - pbeg);
+        gpos = seg_end;
+        __syncthreads();  // the previous segment's readers of wtab / mtab are done
+        const LocusModel* __restrict__ M = P.models + locus;
+        build_tip_table(M, wtab, lane);
+        const ModelRegs R = load_model(M, mtab, lane);
+        const double kappa = mtab[31];
+        const int32_t* __restrict__ work = P.work_cols + P.locus_offsets[locus];
+
+        int next = begin + kSiteBlock;  // wave-uniform: first work index not yet handed to a lane
+        bool done = (begin + lane >= end);
+        int64_t col = work[done ? begin : begin + lane];
+        uint32_t pk[NW > 0 ? NW : 1] = {0};
+#pragma unroll
+        for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
+        double u = 0.0, lo = kUMin, hi = kUMax;
+        bool lo_open = true, hi_open = true;
+        int it = 0;
+        while (true) {
+            double f, g, h;
+            evaluate_column<NW>(P, R, wtab, etab, stack, col, pk, exp(u), f, g, h);
+            if (!done) {
+                ++evals;
+                ++it;
+                int flg = -1;
+                const bool uphill = !(g <= 0.0);
+                // Saturation: beyond this point g is second-order small under first-order rounding noise, its
+                // sign is meaningless; report the policy value s = 1e4 (same rule as the oracle).
+                if (fabs(g) < kFlatEps && fabs(h) < kFlatEps) { flg = TPHIP_FLAG_SATURATED; u = kUMax; }
+                else if (u >= kUMax && uphill) { flg = TPHIP_FLAG_SATURATED; }
+                else if (u <= kUMin && !uphill) { flg = TPHIP_FLAG_ZERO; }
+                else {
+                    if (uphill) { lo = u; lo_open = false; } else { hi = u; hi_open = false; }
+                    double step = (h < 0.0) ? -g / h : (uphill ? kStepMax : -kStepMax);
+                    if (!(step <= kStepMax)) step = kStepMax;
+                    if (step < -kStepMax) step = -kStepMax;
+                    double un = u + step;
+                    // the bracket safeguard must not see a converged (possibly underflowing) Newton step
+                    if (fabs(step) >= kStepTol) {
+                        if (un >= hi) un = hi_open ? kUMax : 0.5 * (lo + hi);
+                        else if (un <= lo) un = lo_open ? kUMin : 0.5 * (lo + hi);
+                        step = un - u;
+                    }
+                    if (fabs(step) < kStepTol) {
+                        f = fma(step, fma(0.5 * h, step, g), f);  // f + g*step + h*step^2/2
+                        flg = TPHIP_FLAG_OK;
+                    }
+                    u = un;
+                    if (flg < 0 && it >= kMaxIt) flg = TPHIP_FLAG_MAXIT;
+                }
+                if (flg >= 0) {  // this column is finished: write it out, the lane becomes free
+                    const double r = exp(u) * kappa;
+                    P.rate[col] = r;
+                    P.subst[col] = r * P.chrono_length;
+                    P.lnl[col] = f;
+                    P.flag[col] = (uint8_t)flg;
+                    done = true;
+                }
             }
-            next += __popcll(free_mask);
-        } else if (free_mask == ~0ull) {
-            break;  // slice exhausted and every lane finished
+            // lane refill: free lanes take the next columns of the segment, in lane order
+            const unsigned long long free_mask = __ballot(done);
+            if (free_mask == 0ull) continue;
+            if (next < end) {
+                const int rank = __popcll(free_mask & ((1ull << lane) - 1ull));
+                const int idx = next + rank;
+                if (done && idx < end) {
+                    col = work[idx];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
+                    u = 0.0; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; it = 0;
+                    done = false;
+                }
+                next += __popcll(free_mask);
+            } else if (free_mask == ~0ull) {
+                break;  // segment exhausted and every lane finished
+            }
         }
     }
     // evaluation count for the FLOP model (one atomic per wave)
@@ -483,7 +602,8 @@ __global__ __launch_bounds__(kSiteBlock) void eval_columns_kernel(EvalParams E) 
         const bool active = want < last;
         const int64_t col = active ? want : first;
         double f, g, h;
-        evaluate_column(P, R, wtab, etab, stack, col, exp(E.u[col]), f, g, h);
+        const uint32_t none[1] = {0};
+        evaluate_column<0>(P, R, wtab, etab, stack, col, none, exp(E.u[col]), f, g, h);
         if (active) { E.f[col] = f; E.g[col] = g; E.h[col] = h; }
     }
 }

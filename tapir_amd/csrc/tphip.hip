@@ -84,10 +84,14 @@ struct tphip_plan {
     DevBuf<TreeOp> d_ops;
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
+    DevBuf<int32_t> d_tip_taxon;
+    int32_t nwords = 0;
     DevBuf<int32_t> d_site_chunk_locus, d_site_chunk_index, d_pi_chunk_locus, d_pi_chunk_index, d_times, d_intervals;
     DevBuf<unsigned long long> d_evals;
     // workspace layout (bytes)
-    size_t ws_work_cols = 0, ws_work_count = 0, ws_partial = 0, ws_total = 0;
+    size_t ws_work_cols = 0, ws_work_count = 0, ws_work_prefix = 0, ws_partial = 0, ws_packed = 0, ws_total = 0;
+    int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
+    int32_t site_persistent = 1;
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev;  // 4 events per slot: site start/stop, pi start/stop
@@ -114,7 +118,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_ops.release(); plan->d_models.release(); plan->d_offsets.release();
     plan->d_locus_pichunk_offsets.release(); plan->d_site_chunk_locus.release(); plan->d_site_chunk_index.release();
     plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
-    plan->d_intervals.release(); plan->d_evals.release();
+    plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release();
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TPHIP_OK;
@@ -157,6 +161,10 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->threshold = d->threshold; p->round_decimals = d->round_decimals; p->correction = d->correction;
     std::string terr = build_tree_program(d->ntaxa, d->nnodes, d->parent, d->branch_len, d->leaf_taxon, &p->prog);
     if (!terr.empty()) { delete p; return fail(TPHIP_ERR_INVALID, "tree: " + terr); }
+    if (p->prog.nleaves != d->ntaxa) {  // HyPhy refuses a tree / alignment mismatch as well
+        delete p;
+        return fail(TPHIP_ERR_INVALID, "tree: the number of leaves differs from the number of alignment rows");
+    }
     const size_t lds_bytes = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     if (lds_bytes > 160 * 1024) { delete p; return fail(TPHIP_ERR_INVALID, "tree needs a deeper LDS stack than 160 KiB allows"); }
     p->h_offsets.assign(d->locus_offsets, d->locus_offsets + d->nloci + 1);
@@ -165,12 +173,8 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     // A slice is what one wave works through with lane refill: long enough to amortise the drain at its end,
     // short enough that the batch still makes >= ~8192 waves (32 per CU).
     {
-        // Target slice length.  Measured on the C2/C3/C4 shapes: the drain at the end of a
-        // slice favours long slices (a 780-column locus cut in two costs +32 %), while a batch of few huge loci
-        // (C3) still needs several thousand waves to balance the last round of the grid.
-        int64_t cc = ncols / 8192;
-        if (cc < 512) cc = 512;
-        if (cc > 1024) cc = 1024;
+        // Target slice length of the non-persistent mode (small batches) and of the eval diagnostic.
+        int64_t cc = 512;
         if (const char* e = getenv("TPHIP_SITE_CHUNK")) {  // tuning knob for experiments
             long v = atol(e);
             if (v >= kSiteBlock) cc = v;
@@ -193,6 +197,10 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     std::vector<int32_t> times(d->times, d->times + d->n_t), iv(d->intervals, d->intervals + 2 * (size_t)d->n_i);
     DevBuf<double> d_pi, d_exch;
     std::vector<double> hpi(d->pi, d->pi + 4 * (size_t)d->nloci), hex(d->exch, d->exch + 6 * (size_t)d->nloci);
+    std::vector<int32_t> tip_taxon;
+    for (const TreeOp& op : p->prog.ops) if (op.code <= OP_TIP_MUL) tip_taxon.push_back(op.taxon);
+    p->nwords = (int32_t)((tip_taxon.size() + 7) / 8);
+    if (e == hipSuccess) e = p->d_tip_taxon.upload(tip_taxon);
     if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
     if (e == hipSuccess) e = p->d_offsets.upload(p->h_offsets);
     if (e == hipSuccess) e = p->d_locus_pichunk_offsets.upload(lpo);
@@ -220,11 +228,31 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         tphip_plan_destroy(p);
         return fail(TPHIP_ERR_HIP, m);
     }
+    {   // persistent grid: exactly the waves the device keeps resident for this LDS footprint
+        hipDeviceProp_t prop;
+        int per_cu = 0;
+        if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) { tphip_plan_destroy(p); return fail(TPHIP_ERR_HIP, "hipGetDeviceProperties failed"); }
+        auto occ = [&](auto kern) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kSiteBlock, lds_bytes); };
+        hipError_t oe;
+        if (p->nwords <= 2) oe = occ(site_rate_kernel<2>);
+        else if (p->nwords <= 8) oe = occ(site_rate_kernel<8>);
+        else if (p->nwords <= 16) oe = occ(site_rate_kernel<16>);
+        else if (p->nwords <= 32) oe = occ(site_rate_kernel<32>);
+        else oe = occ(site_rate_kernel<0>);
+        if (oe != hipSuccess || per_cu < 1) per_cu = 1;
+        p->site_waves = per_cu * prop.multiProcessorCount;
+        // Small batches (an equal share would be under ~1000 columns) run one workgroup per locus-aligned
+        // slice instead: cutting a small locus in two doubles its prologue and drain (measured on C2).
+        p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
+        if (const char* e3 = getenv("TPHIP_SITE_PERSISTENT")) p->site_persistent = (e3[0] == '1');
+    }
     // workspace layout
     size_t off = 0;
     p->ws_work_cols = off; off = align_up(off + sizeof(int32_t) * (size_t)ncols, 256);
     p->ws_work_count = off; off = align_up(off + sizeof(int32_t) * (size_t)d->nloci, 256);
+    p->ws_work_prefix = off; off = align_up(off + sizeof(int64_t) * ((size_t)d->nloci + 1), 256);
     p->ws_partial = off; off = align_up(off + sizeof(double) * (size_t)p->n_pi_chunks * (size_t)(d->T + 2 * d->n_i), 256);
+    p->ws_packed = off; off = align_up(off + sizeof(uint32_t) * (size_t)p->nwords * (size_t)ncols, 256);
     p->ws_total = off + 256;
     *out = p;
     return TPHIP_OK;
@@ -316,9 +344,12 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     C.locus_offsets = p->d_offsets.p; C.chunk_locus = p->d_pi_chunk_locus.p; C.chunk_index = p->d_pi_chunk_index.p;
     C.rate = d_rate; C.subst = d_subst; C.lnl = d_lnl; C.flag = d_flag; C.nres = d_nres;
     C.chrono_length = p->prog.chrono_length;
+    C.tip_taxon = p->d_tip_taxon.p;
+    C.packed = (uint32_t*)((char*)ws + p->ws_packed);
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
         compact_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
+        scan_counts_kernel<<<dim3(1), dim3(1024), 0, st>>>(work_count, p->nloci, (int64_t*)((char*)ws + p->ws_work_prefix));
     }
     HIP_TRY(hipMemsetAsync(p->d_evals.p, 0, sizeof(unsigned long long), st));
     SiteParams S;
@@ -326,13 +357,25 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.nops = (int32_t)p->prog.ops.size(); S.stack_depth = p->prog.stack_depth; S.chrono_length = p->prog.chrono_length;
     S.locus_offsets = p->d_offsets.p; S.chunk_locus = p->d_site_chunk_locus.p; S.chunk_index = p->d_site_chunk_index.p;
     S.chunk_cols = p->site_chunk_cols;
+    S.packed = (const uint32_t*)((char*)ws + p->ws_packed); S.nwords = p->nwords;
     S.work_cols = work_cols; S.work_count = work_count;
+    S.work_prefix = (const int64_t*)((char*)ws + p->ws_work_prefix); S.nloci = p->nloci;
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
-    if (p->n_site_chunks > 0)
-        site_rate_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds, st>>>(S);
+    if (p->n_site_chunks > 0) {
+        const dim3 grid((unsigned)(p->site_persistent ? p->site_waves : p->n_site_chunks)), block(kSiteBlock);
+        S.persistent = p->site_persistent;
+        // register-resident tip states for up to 256 tips; beyond that the byte path (NW = 0)
+        const char* fb = getenv("TPHIP_FORCE_BYTE_PATH");  // test/tuning knob: exercise the NW = 0 kernel on any tree
+        if (fb && fb[0] == '1') site_rate_kernel<0><<<grid, block, lds, st>>>(S);
+        else if (p->nwords <= 2) site_rate_kernel<2><<<grid, block, lds, st>>>(S);
+        else if (p->nwords <= 8) site_rate_kernel<8><<<grid, block, lds, st>>>(S);
+        else if (p->nwords <= 16) site_rate_kernel<16><<<grid, block, lds, st>>>(S);
+        else if (p->nwords <= 32) site_rate_kernel<32><<<grid, block, lds, st>>>(S);
+        else site_rate_kernel<0><<<grid, block, lds, st>>>(S);
+    }
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));
     HIP_TRY(hipGetLastError());
     return TPHIP_OK;
@@ -574,7 +617,8 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     E.S.nops = (int32_t)p->prog.ops.size(); E.S.stack_depth = p->prog.stack_depth; E.S.chrono_length = p->prog.chrono_length;
     E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
     E.S.chunk_cols = p->site_chunk_cols;
-    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
+    E.S.packed = nullptr; E.S.nwords = 0;
+    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
     E.S.flag = nullptr; E.S.eval_counter = nullptr;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);

@@ -270,3 +270,33 @@ def test_all_gap_and_ragged_loci(oracle):
     assert got["lnl"][1] == 0.0 and got["flag"][1] == 1          # all-gap column: L = 1
     assert np.all(got["tables"][0] == 0.0)                       # empty locus -> zero row
     plan.close()
+
+
+@pytest.mark.parametrize("persistent,byte_path", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
+def test_site_rate_kernel_variants(oracle, monkeypatch, persistent, byte_path):
+    """Every scheduling mode (persistent equal shares / locus-aligned slices) and both tip-state paths
+    (register-resident packed words / one-op-ahead byte loads) against the oracle on the same bytes."""
+    engine = _engine()
+    from tapir_amd import synth
+    monkeypatch.setenv("TPHIP_SITE_PERSISTENT", persistent)
+    monkeypatch.setenv("TPHIP_FORCE_BYTE_PATH", byte_path)
+    for ntaxa, nloci, ncols, seed in [(20, 9, 777, 31), (130, 3, 300, 32)]:
+        d = synth.simulate(nloci, ncols, ntaxa, seed)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        st = d["states"].numpy()
+        off = d["locus_offsets"].copy()
+        off[1] = off[0]  # an empty first locus, and loci of different lengths
+        off[2] = off[3] - 5
+        plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, d["pi"], d["exch"], pin["T"], [10], [[5, 15]],
+                           correction=pin["correction"])
+        got = plan.site_rates(st)
+        kappa = plan.models()[3]
+        for l in range(nloci):
+            sl = slice(int(off[l]), int(off[l + 1]))
+            if sl.stop == sl.start:
+                continue
+            ref = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l])
+            assert np.array_equal(got["flag"][sl], ref["flag"])
+            _assert_rates_match(oracle, got, ref, sl, st[:, sl], pin, d["pi"][l], d["exch"][l], kappa[l])
+            assert np.abs(got["lnl"][sl] - ref["lnl"]).max() < 1e-10 * max(1.0, np.abs(ref["lnl"]).max())
+        plan.close()
