@@ -34,7 +34,7 @@ namespace tphip {
 constexpr double kUMin = -23.025850929940457;  // log(1e-10)
 constexpr double kUMax = 9.210340371976184;    // log(1e4)
 constexpr double kStepMax = 2.0;
-constexpr double kStepTol = 1e-9;
+constexpr double kStepTol = 1e-6;   // the last step is applied through the quadratic model: remaining error ~ step^2
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
 constexpr int kSiteBlock = 64;      // one wavefront per workgroup
@@ -513,7 +513,15 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
                 else if (u <= kUMin && !uphill) { flg = TPHIP_FLAG_ZERO; }
                 else {
                     if (uphill) { lo = u; lo_open = false; } else { hi = u; hi_open = false; }
-                    double step = (h < 0.0) ? -g / h : (uphill ? kStepMax : -kStepMax);
+                    // Concave: Newton's -g/h refined to log(1 - g/h), the exact maximiser of m u - a exp(u) + c
+                    // fitted to (g, h) (same rule as the oracle); convex: a capped step uphill.
+                    double step;
+                    if (h < 0.0) {
+                        const double q = 1.0 - g / h;
+                        step = (q > 0.0) ? log(q) : -g / h;
+                    } else {
+                        step = uphill ? kStepMax : -kStepMax;
+                    }
                     if (!(step <= kStepMax)) step = kStepMax;
                     if (step < -kStepMax) step = -kStepMax;
                     double un = u + step;
