@@ -46,7 +46,10 @@
 #define ORC_U_MIN (-23.025850929940457) /* log(1e-10) */
 #define ORC_U_MAX (9.210340371976184)   /* log(1e4)   */
 #define ORC_STEP_MAX 2.0
-#define ORC_STEP_TOL 1e-6 /* the last step is applied through the quadratic model: remaining error ~ step^2 */
+#ifndef ORC_STEP_TOL
+#define ORC_STEP_TOL 3e-4       /* accept when the step is this small: it is then applied with a third-order correction */
+#endif
+#define ORC_STEP_TOL_FIRST 1e-6 /* ... except at the first evaluation, where no second point exists yet */
 #define ORC_MAXIT 100
 #define ORC_FLAT_EPS 1e-10 /* |dlogL/du| and |d2logL/du2| below this: surface flat to fp64 -> saturated */
 
@@ -594,7 +597,8 @@ static void column_loglik(const orc_model *m, const orc_tree *tr, const uint8_t 
 static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
                             double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
     double u = 0, lo = ORC_U_MIN, hi = ORC_U_MAX, f = 0, g, h;
-    int lo_open = 1, hi_open = 1; /* bracket ends not evaluated yet */
+    double u_prev = 0, h_prev = 0;
+    int lo_open = 1, hi_open = 1, have_prev = 0; /* bracket ends not evaluated yet; previous point known */
     *flag_out = 4;
     for (int it = 0; it < ORC_MAXIT; ++it) {
         column_loglik(m, tr, states, ncols, col, u, &f, &g, &h);
@@ -621,19 +625,30 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
         }
         if (!(step <= ORC_STEP_MAX)) step = ORC_STEP_MAX;
         if (step < -ORC_STEP_MAX) step = -ORC_STEP_MAX;
+        const double tol = have_prev ? ORC_STEP_TOL : ORC_STEP_TOL_FIRST;
         double un = u + step;
-        /* the bracket safeguard must not see a converged (possibly underflowing) Newton step */
-        if (fabs(step) >= ORC_STEP_TOL) {
+        /* the bracket safeguard must not see a converged (possibly underflowing) step */
+        if (fabs(step) >= tol) {
             if (un >= hi) un = hi_open ? ORC_U_MAX : 0.5 * (lo + hi);
             else if (un <= lo) un = lo_open ? ORC_U_MIN : 0.5 * (lo + hi);
             step = un - u;
         }
-        if (fabs(step) < ORC_STEP_TOL) { /* converged: take the last step with its quadratic model */
-            f += g * step + 0.5 * h * step * step;
-            u = un;
+        if (fabs(step) < tol) {
+            /* Converged.  Rather than spend one more evaluation to watch the step shrink from ~1e-4 to ~1e-8,
+             * the last step gets its third-order correction: the third derivative f3 from the two most recent
+             * curvatures (the step's own model already carries f3 = h), leaving an error of O(step^3), i.e.
+             * ~1e-8 or less in u. */
+            double f3 = h;
+            if (have_prev && h < 0) {
+                f3 = (h - h_prev) / (u - u_prev);
+                step -= 0.5 * ((f3 - h) / h) * step * step;
+            }
+            f += step * (g + step * (0.5 * h + step * (f3 / 6.0)));
+            u += step;
             *flag_out = 0;
             break;
         }
+        u_prev = u; h_prev = h; have_prev = 1;
         u = un;
     }
     *s_out = exp(u);

@@ -34,7 +34,8 @@ namespace tphip {
 constexpr double kUMin = -23.025850929940457;  // log(1e-10)
 constexpr double kUMax = 9.210340371976184;    // log(1e4)
 constexpr double kStepMax = 2.0;
-constexpr double kStepTol = 1e-6;   // the last step is applied through the quadratic model: remaining error ~ step^2
+constexpr double kStepTol = 3e-4;       // accept when the step is this small: applied with a third-order correction
+constexpr double kStepTolFirst = 1e-6;  // ... except at the first evaluation (no second point yet)
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
 constexpr int kSiteBlock = 64;      // one wavefront per workgroup
@@ -495,8 +496,8 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
         uint32_t pk[NW > 0 ? NW : 1] = {0};
 #pragma unroll
         for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
-        double u = 0.0, lo = kUMin, hi = kUMax;
-        bool lo_open = true, hi_open = true;
+        double u = 0.0, lo = kUMin, hi = kUMax, u_prev = 0.0, h_prev = 0.0;
+        bool lo_open = true, hi_open = true, have_prev = false;
         int it = 0;
         while (true) {
             double f, g, h;
@@ -524,17 +525,27 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
                     }
                     if (!(step <= kStepMax)) step = kStepMax;
                     if (step < -kStepMax) step = -kStepMax;
+                    const double tol = have_prev ? kStepTol : kStepTolFirst;
                     double un = u + step;
-                    // the bracket safeguard must not see a converged (possibly underflowing) Newton step
-                    if (fabs(step) >= kStepTol) {
+                    // the bracket safeguard must not see a converged (possibly underflowing) step
+                    if (fabs(step) >= tol) {
                         if (un >= hi) un = hi_open ? kUMax : 0.5 * (lo + hi);
                         else if (un <= lo) un = lo_open ? kUMin : 0.5 * (lo + hi);
                         step = un - u;
                     }
-                    if (fabs(step) < kStepTol) {
-                        f = fma(step, fma(0.5 * h, step, g), f);  // f + g*step + h*step^2/2
+                    if (fabs(step) < tol) {
+                        // Converged: the last step gets its third-order correction (third derivative f3 from the two
+                        // most recent curvatures) instead of one more evaluation -- same rule as the oracle.
+                        double f3 = h;
+                        if (have_prev && h < 0.0) {
+                            f3 = (h - h_prev) / (u - u_prev);
+                            step -= 0.5 * ((f3 - h) / h) * step * step;
+                        }
+                        f = fma(step, fma(step, fma(step, f3 / 6.0, 0.5 * h), g), f);
+                        un = u + step;
                         flg = TPHIP_FLAG_OK;
                     }
+                    u_prev = u; h_prev = h; have_prev = true;
                     u = un;
                     if (flg < 0 && it >= kMaxIt) flg = TPHIP_FLAG_MAXIT;
                 }
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
                     col = work[idx];
 #pragma unroll
                     for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
-                    u = 0.0; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; it = 0;
+                    u = 0.0; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; have_prev = false; it = 0;
                     done = false;
                 }
                 next += __popcll(free_mask);
