@@ -132,6 +132,28 @@ def main():
     alg_bytes = n * (ntaxa + 24)  # per launch of the dominant kernel, this rank
     achieved = alg_bytes / (site_avg_ms * 1e-3) / 1e9 if site_avg_ms > 0 else 0.0
 
+    # what the HBM roof is on this very device: a device-to-device copy of 1 GiB (read + write counted)
+    hbm_copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        hbm_copy_gbs = 5 * 2 * (1 << 30) / (time.perf_counter() - t1) / 1e9
+        del src, dst
+
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass of this workload
+    # (profiles/: separate --pmc passes, FETCH_SIZE calibrated on classify_kernel's known byte count)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            traffic = json.load(fh).get(args.workload, {}).get("site_rate_kernel_bytes")
+
     flags = torch.bincount(d_flag.to(torch.int64), minlength=5).cpu().numpy().tolist()
     fl_eval = flops_per_eval(plan.op_counts)
     fp64_tflops = evals * fl_eval / (site_avg_ms * 1e-3) / 1e12 if site_avg_ms > 0 else 0.0
@@ -160,9 +182,11 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": "site_rate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": site_avg_ms,
-            "note": "BASELINE.json mandates the HBM figure; the path is FP64-VALU bound (see fp64)",
+            "hbm_copy_measured_gbs": hbm_copy_gbs,
+            "note": "BASELINE.json mandates the HBM figure; the path is FP64-VALU bound (see fp64); traffic = PMC "
+                    "FETCH_SIZE (calibrated) + WRITE_SIZE bytes per launch from profiles/pmc_traffic.json",
         },
         "fp64": {
             "evals_per_launch": evals, "evals_per_column": evals / max(1, n), "flop_per_eval_model": fl_eval,
