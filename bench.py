@@ -63,9 +63,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        tdist.init_process_group("nccl")
+    # under torch.distributed.run (RANK set) the RCCL path is used even with one rank, so that a 1-GPU torchrun
+    # exercises exactly the code the 8-GPU run executes
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     nloci_full, ncols, ntaxa, times, intervals = synth.WORKLOADS[args.workload]
     # per-GPU share: C2/C3 are single-GPU configs (whole config per GPU); C4/C5 are 8-GPU configs (1/8 per GPU)
@@ -93,16 +99,16 @@ def main():
     d_nres = torch.empty(n, dtype=torch.int32, device=dev)
     d_tables = torch.empty((nloci, W), dtype=torch.float64, device=dev)
     d_ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * nloci, W), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((world * nloci, W), dtype=torch.float64, device=dev) if use_dist else None
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         plan.run_dev(d_states, d_rate, d_subst, d_lnl, d_flag, d_nres, d_tables, d_ws, stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, d_tables)
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, d_tables)  # the one collective: [L/G, W] PI tables per rank
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -118,7 +124,7 @@ def main():
     elapsed = time.perf_counter() - t0
     site_ms, pi_ms, launches = plan.profile_read(reset=True)
     plan.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -202,8 +208,11 @@ def main():
         out["cpu_baseline"] = cpu_baseline(plan, data, pin, nloci, ncols, ntaxa, times, intervals, args, d_rate, d_nres)
     if rank == 0:
         print(json.dumps(out))
+    if use_dist:
+        # every rank's rows are in `gathered`; rank r's block must be bit-identical to its own table
+        assert torch.equal(gathered[rank * nloci:(rank + 1) * nloci], d_tables)
     plan.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
