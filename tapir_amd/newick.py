@@ -34,7 +34,6 @@ def parse(text):
     if not text:
         raise NewickError("empty tree string")
     n = len(text)
-    pos = 0
     root = Node()
     cur = root
     # iterative descent (caterpillar trees can be thousands of levels deep)

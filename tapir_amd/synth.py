@@ -9,7 +9,6 @@ The generator runs in torch so the big shapes can be produced directly in HBM (d
 streams of the CPU and GPU generators differ, so parity tests and the CPU baseline always take the bytes
 one generator made and hand the SAME bytes to both sides.
 """
-import math
 
 import numpy as np
 
@@ -100,7 +99,6 @@ def simulate(nloci, ncols, ntaxa, seed, device="cpu", gap_frac=0.05, rate_shape=
     pi, exch = locus_parameters(nloci, seed)
     lam, U, Ui = _eigen(pi, exch)
     order = newick.postorder(root)
-    idx = {id(n): i for i, n in enumerate(order)}
     leaf_row = {id(n): names.index(n.name) for n in order if n.is_leaf()}
     dev = torch.device(device)
     total = nloci * ncols
@@ -143,7 +141,6 @@ def simulate(nloci, ncols, ntaxa, seed, device="cpu", gap_frac=0.05, rate_shape=
                 g = torch.rand((n,), generator=gen, dtype=torch.float64, device=dev) < gap_frac
                 mask = torch.where(g, torch.full_like(st, 15), torch.bitwise_left_shift(torch.ones_like(st), st))
                 states[leaf_row[id(node)], l0 * ncols:l1 * ncols] = mask.to(torch.uint8)
-            # free the parent's state once all its children are drawn
         del node_state
     offsets = np.arange(nloci + 1, dtype=np.int64) * ncols
     return dict(states=states, locus_offsets=offsets, pi=pi, exch=exch, root=root, names=names, true_rates=rates_out)
