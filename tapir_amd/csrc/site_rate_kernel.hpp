@@ -210,7 +210,7 @@ __device__ __forceinline__ void tip_message(const ModelRegs& R, const double* __
 }
 
 // acc <- P(t s) * acc with derivatives (internal branch)
-__device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* __restrict__ etab, double ts, Partial& p) {
+__device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* __restrict__ etab, double ts, double f, Partial& p) {
     double w0[4], w1[4], w2[4];
     w0[0] = fma(R.pi[3], p.v[3], fma(R.pi[2], p.v[2], fma(R.pi[1], p.v[1], R.pi[0] * p.v[0])));
     w1[0] = fma(R.pi[3], p.d1[3], fma(R.pi[2], p.d1[2], fma(R.pi[1], p.d1[1], R.pi[0] * p.d1[0])));
@@ -222,11 +222,12 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* _
         w1[k] = fma(Ir[3], p.d1[3], fma(Ir[2], p.d1[2], fma(Ir[1], p.d1[1], Ir[0] * p.d1[0])));
         w2[k] = fma(Ir[3], p.d2[3], fma(Ir[2], p.d2[2], fma(Ir[1], p.d2[1], Ir[0] * p.d2[0])));
     }
+    const double z0 = w0[0] * f, z1 = w1[0] * f, z2 = w2[0] * f;  // eigenvalue 0: e = 1
     double a[3], b[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         double x = R.lam[k] * ts;
-        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
+        double e = (kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x)) * f;
         a[k] = e * w0[k + 1];
         double ew1 = e * w1[k + 1], ew2 = e * w2[k + 1];
         b[k] = fma(x, a[k], ew1);
@@ -235,27 +236,27 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double* Ur = R.U + i * 3;
-        p.v[i] = fma(Ur[2], a[2], fma(Ur[1], a[1], fma(Ur[0], a[0], w0[0])));
-        p.d1[i] = fma(Ur[2], b[2], fma(Ur[1], b[1], fma(Ur[0], b[0], w1[0])));
-        p.d2[i] = fma(Ur[2], c[2], fma(Ur[1], c[1], fma(Ur[0], c[0], w2[0])));
+        p.v[i] = fma(Ur[2], a[2], fma(Ur[1], a[1], fma(Ur[0], a[0], z0)));
+        p.d1[i] = fma(Ur[2], b[2], fma(Ur[1], b[1], fma(Ur[0], b[0], z1)));
+        p.d2[i] = fma(Ur[2], c[2], fma(Ur[1], c[1], fma(Ur[0], c[0], z2)));
     }
 }
 
-// Rescale when the partial gets small (deep trees / hundreds of taxa); exponent goes to `scale`.
-// Partials are non-negative, so their high words order like unsigned integers: the test is two integer max3
-// and one compare instead of three FP64 max and an exponent extraction.
-__device__ __forceinline__ void partial_rescale(Partial& p, int& scale) {
+// Rescaling for deep trees / hundreds of taxa: when the largest component of the running partial is below 2^-256
+// the NEXT message it meets is multiplied by 2^-e (returned here, 1.0 otherwise) and e is added to `scale`.
+// Everything downstream is linear in that message, so folding the factor into it (4 multiplies on a tip's
+// U^-1 row, 6 on a branch) rescales value and both derivatives without a branch and without touching the 12
+// accumulator registers (a conditional in-place multiply made the compiler copy all of them on every op).
+// Partials are non-negative, so their high words order like unsigned integers.
+__device__ __forceinline__ double rescale_factor(const Partial& p, int& scale) {
     const unsigned h0 = (unsigned)__double2hiint(p.v[0]), h1 = (unsigned)__double2hiint(p.v[1]);
     const unsigned h2 = (unsigned)__double2hiint(p.v[2]), h3 = (unsigned)__double2hiint(p.v[3]);
     const unsigned mx = max(max(h0, h1), max(h2, h3));
     const unsigned kLow = (unsigned)(1023 - 256) << 20;  // 2^-256
-    if (mx < kLow && mx >= (1u << 20)) {                 // below 2^-256 and still a normal number
-        const int e = (int)(mx >> 20) - 1023;
-        const double f = __hiloint2double((1023 - e) << 20, 0);  // 2^-e
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { p.v[i] *= f; p.d1[i] *= f; p.d2[i] *= f; }
-        scale += e;
-    }
+    const bool need = (mx < kLow && mx >= (1u << 20));   // below 2^-256 and still a normal number
+    const int e = need ? (int)(mx >> 20) - 1023 : 0;
+    scale += e;
+    return __hiloint2double((1023 - e) << 20, 0);        // 2^-e
 }
 
 __device__ __forceinline__ unsigned load_state(const SiteParams& P, int taxon, int64_t col) {
@@ -361,14 +362,14 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
                     mask = mask ? mask : 15u;
                 }
                 const double* w = wtab + mask * 4;
-                const double wv[4] = {w[0], w[1], w[2], w[3]};
+                const double f = rescale_factor(acc, scale);
+                const double wv[4] = {w[0] * f, w[1] * f, w[2] * f, w[3] * f};
                 tip_message(R, etab, wv, op.t * s, m);
             }
-            partial_rescale(acc, scale);
             partial_mul(acc, m);
         } else if (op.code == OP_BRANCH) {
-            partial_rescale(acc, scale);
-            branch_apply(R, etab, op.t * s, acc);
+            const double f = rescale_factor(acc, scale);
+            branch_apply(R, etab, op.t * s, f, acc);
         } else {  // OP_PUSH: park the finished sibling, start the next subtree from the identity
             double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
 #pragma unroll

@@ -245,6 +245,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         // slice instead: cutting a small locus in two doubles its prologue and drain (measured on C2).
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
         if (const char* e3 = getenv("TPHIP_SITE_PERSISTENT")) p->site_persistent = (e3[0] == '1');
+        if (const char* e2 = getenv("TPHIP_SITE_WAVES")) { long v = atol(e2); if (v >= 1) p->site_waves = (int32_t)v; }  // tuning knob
     }
     // workspace layout
     size_t off = 0;
