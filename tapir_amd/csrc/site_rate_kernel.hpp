@@ -259,6 +259,24 @@ __device__ __forceinline__ double rescale_factor(const Partial& p, int& scale) {
     return __hiloint2double((1023 - e) << 20, 0);        // 2^-e
 }
 
+// Hand-issued scalar load of one TreeOp (16 bytes) and its explicit wait; see evaluate_column.
+typedef int SOp __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ SOp sop_issue(const TreeOp* p) {  // p must be wave-uniform
+    SOp r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ void sop_wait(SOp& r) {  // ties every later use of r behind the wait
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r));
+}
+__device__ __forceinline__ TreeOp sop_decode(const SOp& r) {
+    TreeOp o;
+    o.code = r.x;
+    o.taxon = r.y;
+    o.t = __hiloint2double(r.w, r.z);
+    return o;
+}
+
 __device__ __forceinline__ unsigned load_state(const SiteParams& P, int taxon, int64_t col) {
     return P.states[(int64_t)taxon * P.ncols_total + col];
 }
@@ -317,21 +335,28 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
     const int lane = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc.v[i] = 1.0; acc.d1[i] = 0.0; acc.d2[i] = 0.0; }
-    // The op stream is read through the constant address space: it is never written while the kernel runs,
-    // and this is what lets the compiler use scalar loads (s_load) although the kernel also stores results.
-    typedef const TreeOp __attribute__((address_space(4))) * ConstOps;
-    ConstOps ops = (ConstOps)(uintptr_t)P.ops;
+    // The op stream is fetched two ops ahead by hand-issued scalar loads (s_load_dwordx4 = one 16-byte TreeOp).
+    // Through plain C++ the compiler either turns the fetch into a vector load (the kernel also stores, so the
+    // pointer is not provably invariant) or, via the constant address space, into an s_load that it waits for
+    // immediately; issued here and waited for at the END of the op (sop_wait), the ~100-cycle scalar-cache round
+    // trip disappears under the op's FP64 work.  A hidden SMEM op in flight only makes the compiler's own
+    // lgkmcnt waits for LDS more conservative, never unsafe (cdna_hip_programming.md section 5.7).
+    const TreeOp* __restrict__ ops = P.ops;
     const int last = P.nops - 1;
     TreeOp op, nxt;
-    op.code = ops[0].code; op.taxon = ops[0].taxon; op.t = ops[0].t;
-    { const int i1 = last < 1 ? last : 1; nxt.code = ops[i1].code; nxt.taxon = ops[i1].taxon; nxt.t = ops[i1].t; }
+    {
+        SOp r0 = sop_issue(ops), r1 = sop_issue(ops + (last < 1 ? last : 1));
+        sop_wait(r0);
+        sop_wait(r1);
+        op = sop_decode(r0);
+        nxt = sop_decode(r1);
+    }
     unsigned st = 15u;
     if constexpr (NW == 0) st = load_state(P, op.taxon, col);  // the program always starts at a tip
     for (int ip = 0; ip < P.nops; ++ip) {
         // Two-deep fetch pipeline: op ip+2 (scalar load) and, on the byte path, the state of op ip+1 are issued
         // here and consumed one iteration later, i.e. they stay in flight under this op's FP64 work.
-        TreeOp nn;
-        { const int i2 = (ip + 2 < last) ? ip + 2 : last; nn.code = ops[i2].code; nn.taxon = ops[i2].taxon; nn.t = ops[i2].t; }
+        SOp raw = sop_issue(ops + ((ip + 2 < last) ? ip + 2 : last));
         unsigned st_nxt = 15u;
         if constexpr (NW == 0) {
             if (nxt.code <= OP_TIP_MUL) st_nxt = load_state(P, nxt.taxon, col);
@@ -381,8 +406,9 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
             }
             ++sp;
         }
+        sop_wait(raw);
         op = nxt;
-        nxt = nn;
+        nxt = sop_decode(raw);
         st = st_nxt;
     }
     double L = 0, L1 = 0, L2 = 0;
