@@ -42,52 +42,100 @@ struct ClassifyParams {
     uint32_t* packed;             // [ceil(ntaxa/8)][ncols_total] out: 8 four-bit masks per word, program tip order
 };
 
-// One thread per column; a wave reads 64 consecutive bytes of each taxon row.
+// Per-column bookkeeping shared by the two load paths of classify_kernel.
+struct ColumnScan {
+    unsigned uni = 0, word = 0;
+    int resolved = 0, informative = 0;
+    __device__ __forceinline__ void tip(unsigned m, int k) {
+        m &= 15u;
+        m = m ? m : 15u;
+        const bool res = (m != 15u);
+        uni |= res ? m : 0u;
+        resolved += res;
+        informative += (__popc(m) == 1);
+        word |= m << (4 * (k & 7));
+    }
+};
+
+__device__ __forceinline__ void classify_finish(const ClassifyParams& P, const LocusModel* __restrict__ M, int64_t col,
+                                                const ColumnScan& c, uint8_t& flg_out) {
+    uint8_t flg = TPHIP_FLAG_OK;  // provisional: site_rate_kernel will overwrite
+    if (c.resolved <= 1) flg = TPHIP_FLAG_FLAT;
+    else if (__popc(c.uni) == 1) flg = TPHIP_FLAG_ZERO;
+    flg_out = flg;
+    if (flg != TPHIP_FLAG_OK) {
+        // L = sum over the states allowed by the one informative mask of pi_x (1 if nothing is resolved)
+        double L = 0;
+        if (c.uni == 0) L = 1.0;
+        else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) L += ((c.uni >> x) & 1u) ? M->pi[x] : 0.0;
+        }
+        const double s = (flg == TPHIP_FLAG_FLAT) ? 1.0 : 0.0;  // flat: siteRate keeps its start value (bf:1050)
+        const double r = s * M->kappa;
+        P.rate[col] = r;
+        P.subst[col] = r * P.chrono_length;
+        P.lnl[col] = log(L);
+    }
+}
+
+// HBM-bound byte kernel.  Each thread owns 4 CONSECUTIVE columns: when the row addresses are 4-byte aligned
+// (alignment of the states pointer, of ncols_total and of the locus offset: true for every BASELINE shape) a taxon
+// row is read as one dword per lane (256 B per wave instruction instead of 64), the packed tip words and the
+// counts go out as one 16-byte store per lane and the four flags as one dword.  Unaligned batches fall back to
+// byte accesses with the same thread-to-column map.  Tips are visited in tree-program order so that the same
+// pass emits the packed words site_rate_kernel keeps in registers.
 __global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
     const int locus = P.chunk_locus[blockIdx.x];
     const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
     const LocusModel* __restrict__ M = P.models + locus;
-    const int64_t base = lo + (int64_t)P.chunk_index[blockIdx.x] * kPiChunk;
-#pragma unroll
-    for (int j = 0; j < kPiColsPerThread; ++j) {
-        const int64_t col = base + j * kPiBlock + threadIdx.x;
-        if (col >= hi) continue;
-        unsigned uni = 0, word = 0;
-        int resolved = 0, informative = 0;
-        const uint8_t* p = P.states + col;
+    const int64_t c0 = lo + (int64_t)P.chunk_index[blockIdx.x] * kPiChunk + 4 * (int64_t)threadIdx.x;
+    if (c0 >= hi) return;
+    const bool full = (c0 + 4 <= hi);
+    const bool aligned = full && ((reinterpret_cast<uintptr_t>(P.states) & 3u) == 0) && ((P.ncols_total & 3) == 0) &&
+                         ((c0 & 3) == 0);
+    ColumnScan c[4];
+    if (aligned) {
         for (int k = 0; k < P.ntaxa; ++k) {
-            const int t = P.tip_taxon[k];  // uniform -> scalar load; visiting tips in program order lets the same
-                                           // pass emit the packed words site_rate_kernel keeps in registers
-            unsigned m = p[(int64_t)t * P.ncols_total] & 15u;
-            m = m ? m : 15u;
-            const bool res = (m != 15u);
-            uni |= res ? m : 0u;
-            resolved += res;
-            informative += (__popc(m) == 1);
-            word |= m << (4 * (k & 7));
+            const int t = P.tip_taxon[k];  // uniform -> scalar load
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(P.states + (int64_t)t * P.ncols_total + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j].tip((v >> (8 * j)) & 0xffu, k);
             if ((k & 7) == 7 || k == P.ntaxa - 1) {
-                P.packed[(int64_t)(k >> 3) * P.ncols_total + col] = word;
-                word = 0;
+                uint4 w = make_uint4(c[0].word, c[1].word, c[2].word, c[3].word);
+                *reinterpret_cast<uint4*>(P.packed + (int64_t)(k >> 3) * P.ncols_total + c0) = w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j].word = 0;
             }
         }
-        P.nres[col] = informative;
-        uint8_t flg = TPHIP_FLAG_OK;  // provisional: site_rate_kernel will overwrite
-        if (resolved <= 1) flg = TPHIP_FLAG_FLAT;
-        else if (__popc(uni) == 1) flg = TPHIP_FLAG_ZERO;
-        P.flag[col] = flg;
-        if (flg != TPHIP_FLAG_OK) {
-            // L = sum over the states allowed by the one informative mask of pi_x (1 if nothing is resolved)
-            double L = 0;
-            if (uni == 0) L = 1.0;
-            else {
+        uint8_t f[4];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) L += ((uni >> x) & 1u) ? M->pi[x] : 0.0;
+        for (int j = 0; j < 4; ++j) classify_finish(P, M, c0 + j, c[j], f[j]);
+        *reinterpret_cast<int4*>(P.nres + c0) = make_int4(c[0].informative, c[1].informative, c[2].informative, c[3].informative);
+        *reinterpret_cast<uint32_t*>(P.flag + c0) = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
+    } else {
+        const int n = full ? 4 : (int)(hi - c0);
+        for (int k = 0; k < P.ntaxa; ++k) {
+            const int t = P.tip_taxon[k];
+            const uint8_t* row = P.states + (int64_t)t * P.ncols_total + c0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j < n) c[j].tip(row[j], k);
+            if ((k & 7) == 7 || k == P.ntaxa - 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < n) P.packed[(int64_t)(k >> 3) * P.ncols_total + c0 + j] = c[j].word;
+                    c[j].word = 0;
+                }
             }
-            const double s = (flg == TPHIP_FLAG_FLAT) ? 1.0 : 0.0;  // flat: siteRate keeps its start value (bf:1050)
-            const double r = s * M->kappa;
-            P.rate[col] = r;
-            P.subst[col] = r * P.chrono_length;
-            P.lnl[col] = log(L);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < n) {
+                uint8_t f;
+                classify_finish(P, M, c0 + j, c[j], f);
+                P.nres[c0 + j] = c[j].informative;
+                P.flag[c0 + j] = f;
+            }
         }
     }
 }
