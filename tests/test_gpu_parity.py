@@ -300,3 +300,44 @@ def test_site_rate_kernel_variants(oracle, monkeypatch, persistent, byte_path):
             _assert_rates_match(oracle, got, ref, sl, st[:, sl], pin, d["pi"][l], d["exch"][l], kappa[l])
             assert np.abs(got["lnl"][sl] - ref["lnl"]).max() < 1e-10 * max(1.0, np.abs(ref["lnl"]).max())
         plan.close()
+
+
+def test_hyphy_protocol_shim(golden_dir, tmp_path, oracle):
+    """Boundary #1: `--hyphy /path/to/tphip_hyphy` -- argv = [exe, template], three stdin lines, JSON
+    file out, stdout must not start with "Error"; the file must parse the way tapir/compute.py:24-44 parses it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    _engine()
+    from tapir_amd import compute, newick
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    depth, factor, tree = compute.correct_branch_lengths(os.path.join(golden_dir, "Euteleost.tree"), "newick", d=str(tmp_path))
+    out = str(tmp_path / "chr1_918.nex.rates")
+    towrite = "\n".join([os.path.join(golden_dir, "chr1_918.nex"), tree, out])
+    env = dict(os.environ, TPHIP_EXCHANGEABILITIES="0.96,1,0.58,0.36,1.87,0.51")
+    p = subprocess.run([sys.executable, os.path.join(root, "bin", "tphip_hyphy"), "models_and_rates.bf"], input=towrite,
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0 and not p.stdout.startswith("Error"), p.stdout[:500] + p.stderr[-500:]
+    rates = compute.parse_site_rates(out, correction=factor)      # rewrites the file with corrected_rates
+    doc = json.load(open(out))
+    assert len(doc["sites"]["rates"]) == 226 and len(doc["sites"]["corrected_rates"]) == 226
+    got = np.array([r["rate"] for r in doc["sites"]["rates"]])
+    # same numbers as the oracle fed with the file's own (empirical) base frequencies
+    from tapir_amd import nexus
+    names, st = nexus.read_states(os.path.join(golden_dir, "chr1_918.nex"))
+    troot = newick.read_tree(tree)
+    leaf_names = [n.name for n in newick.leaves(troot)]
+    parent, blen, leaf = newick.to_arrays(troot, leaf_names)
+    st = st[[names.index(n) for n in leaf_names]]
+    # the file prints pi with 6 significant digits (HyPhy's default print precision); the engine used full precision
+    pi = nexus.base_frequencies_from_histogram(np.bincount(st.ravel(), minlength=16)[None, :16])[0]
+    ref = oracle.site_rates(st, parent, blen, leaf, pi, [0.96, 1, 0.58, 0.36, 1.87, 0.51])
+    ok = (ref["flag"] == 0) | (ref["flag"] == 3)
+    assert np.abs(got - ref["rate"])[ok].max() < 5.1e-5
+    assert np.abs(np.array([r["ll"] for r in doc["sites"]["rates"]]) - ref["lnl"]).max() < 5.1e-5
+    assert np.allclose(rates, got / factor)
+    # a missing alignment must surface as an "Error" on stdout, which tapir turns into "hyphy error: ..."
+    p = subprocess.run([sys.executable, os.path.join(root, "bin", "tphip_hyphy"), "x.bf"], input="nope.nex\n%s\n%s" % (tree, out),
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.stdout.startswith("Error")
