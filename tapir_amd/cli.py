@@ -3,8 +3,8 @@ per-locus HyPhy loop replaced by one batched call into the HIP engine.
 
 Same positionals, same required/optional flags and defaults, same output directory contents
 (Tree_<factor>_<depth>.newick, <alignment>.rates JSON per locus, phylogenetic-informativeness.sqlite).
-`--hyphy`, `--template` and `--multiprocessing` are accepted for compatibility and ignored (there is no
-subprocess and no process pool).  New, opt-in flags only: --device, --exchangeabilities / --subs-model,
+`--hyphy` and `--template` are accepted for compatibility and ignored (there is no subprocess);
+`--multiprocessing` parallelises the host side only (NEXUS parsing, .rates files).  New, opt-in flags only: --device, --exchangeabilities / --subs-model,
 --integral-mode, --full-precision-rates.
 
 Stage 1 of the HyPhy script (203-model fit + model averaging of the GTR exchangeabilities,
@@ -40,7 +40,8 @@ def get_args(argv=None):
     parser.add_argument('--template', help="Ignored (kept for compatibility)", default=None)
     parser.add_argument('--threshold', help="""Minimum number of taxa without
         a gap for a site to be considered informative""", default=3, type=int)
-    parser.add_argument('--multiprocessing', help="Ignored (kept for compatibility): loci are batched on the GPU",
+    parser.add_argument('--multiprocessing', help="""Enable parallel
+        reading of alignments and writing of site-rate files (the rates themselves are always batched on the GPU)""",
                         default=False, action='store_true')
     parser.add_argument('--site-rates', default=False, action='store_true',
                         help="Use previously calculated site rates")
@@ -129,6 +130,10 @@ def main(argv=None, engine_mod=None):
     leaf_names = [n.name for n in newick.leaves(root)]
     parent, blen, leaf = newick.to_arrays(root, leaf_names)
     integ_mode = 0 if args.integral_mode == 'quadpack' else 1
+    workers = 1
+    if args.multiprocessing:  # the reference: Pool(processes = cpu_count() - 1), bin/tapir_compute.py:162-163
+        from multiprocessing import cpu_count
+        workers = max(1, cpu_count() - 1)
     if not args.site_rates:
         print("\nEstimating site rates and PI for files:")
         alignments = base.get_files(args.alignments, '*.nex,*.nexus')
@@ -144,7 +149,7 @@ def main(argv=None, engine_mod=None):
                                          correction, args.threshold, exch, pi=pi, subsets=subset_pi,
                                          output_dir=args.output, device=args.device, integ_mode=integ_mode,
                                          round_decimals=-1 if args.full_precision_rates else 4,
-                                         engine_mod=engine_mod, progress=pipeline.dot_progress)
+                                         engine_mod=engine_mod, progress=pipeline.dot_progress, workers=workers)
     else:
         print("Estimating PI for files (--site-rate option):")
         rate_files = base.get_files(args.alignments, '*.rates')

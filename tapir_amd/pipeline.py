@@ -7,7 +7,6 @@ batch (taxon-major state masks + CSR locus offsets), one call into the HIP engin
 `<alignment>.rates` JSON files (schema of models_and_rates.bf:1018-1104 plus `corrected_rates`,
 tapir/compute.py:40-43) and worker()-shaped result tuples for tapir_amd.db.
 """
-import json
 import os
 import sys
 
@@ -20,14 +19,23 @@ class PipelineError(Exception):
     pass
 
 
-def load_alignments(paths, leaf_names):
+def _read_one(path):
+    return nexus.read_states(path)
+
+
+def load_alignments(paths, leaf_names, workers=1):
     """Read NEXUS alignments and flatten them: returns (states uint8 [ntaxa, ncols_total], offsets int64[L+1]).
     Rows follow `leaf_names` (the tree's leaves); an alignment must hold exactly those taxa, as HyPhy
-    requires of (siteFilter, siteTree)."""
+    requires of (siteFilter, siteTree).  workers > 1 parses files in a process pool (--multiprocessing)."""
+    if workers > 1 and len(paths) > 1:
+        import multiprocessing
+        with multiprocessing.get_context("fork").Pool(workers) as pool:
+            parsed = pool.map(_read_one, paths, chunksize=max(1, len(paths) // (8 * workers)))
+    else:
+        parsed = [_read_one(p) for p in paths]
     blocks, offsets = [], [0]
     want = set(leaf_names)
-    for p in paths:
-        names, st = nexus.read_states(p)
+    for p, (names, st) in zip(paths, parsed):
         have = set(names)
         if have != want:
             missing, extra = sorted(want - have), sorted(have - want)
@@ -53,9 +61,43 @@ def format_rates_json(freqs, exch, site, subst, rate, ll, corrected):
     }}
 
 
+def dumps_rates_json(freqs, exch, site, subst, rate, ll, corrected):
+    """The text `json.dumps(format_rates_json(...), indent=4)` would produce, built by bulk string formatting:
+    the generic encoder spends ~30 us per site (it dominated the whole CLI), this ~1 us."""
+    f4 = lambda arr: [repr(float("%.4f" % v)) for v in arr]  # noqa: E731  (json writes floats with float.__repr__)
+    sub, rat, lls = f4(subst), f4(rate), f4(ll)
+    cor = [repr(float(v)) for v in corrected]
+    sites = [int(x) for x in site]
+    head = ('{\n    "sites": {\n        "freqs": {\n            "A": %s,\n            "C": %s,\n            "G": %s,\n'
+            '            "T": %s\n        },\n        "subs_matrix": {\n            "AC": %s,\n            "AG": %s,\n'
+            '            "AT": %s,\n            "CG": %s,\n            "CT": %s,\n            "GT": %s\n        },\n'
+            % tuple(repr(float(x)) for x in list(freqs) + list(exch)))
+    if sites:
+        rows = ",\n".join('            {\n                "site": %d,\n                "subst": %s,\n                "rate": %s,\n'
+                          '                "ll": %s\n            }' % t for t in zip(sites, sub, rat, lls))
+        crow = ",\n".join('            {\n                "site": %d,\n                "rate": %s\n            }' % t
+                          for t in zip(sites, cor))
+        body = '        "rates": [\n%s\n        ],\n        "corrected_rates": [\n%s\n        ]\n' % (rows, crow)
+    else:
+        body = '        "rates": [],\n        "corrected_rates": []\n'
+    return head + body + "    }\n}"
+
+
+_WRITE_CTX = None
+
+
+def _write_one(l):
+    alignments, offsets, pi, exch, subst, rate4, lnl, corrected, output_dir = _WRITE_CTX
+    sl = slice(offsets[l], offsets[l + 1])
+    n = offsets[l + 1] - offsets[l]
+    with open(os.path.join(output_dir, os.path.basename(alignments[l]) + ".rates"), "w") as fh:
+        fh.write(dumps_rates_json(pi[l], exch[l], np.arange(1, n + 1), subst[sl], rate4[sl], lnl[sl], corrected[sl]))
+    return l
+
+
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
                    exch, pi=None, subsets=None, output_dir=None, device=0, integ_mode=0, round_decimals=4,
-                   engine_mod=None, progress=None):
+                   engine_mod=None, progress=None, workers=1):
     """Site rates + PI for a list of NEXUS alignments.  Returns a list of worker()-shaped tuples
     (alignment, rates, mean_rate, None, pi_net, pi_times, pi_epochs) in the order of `alignments`.
 
@@ -64,7 +106,7 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     if eng is None:
         from . import engine as eng
     subsets = subsets or {}
-    states, offsets = load_alignments(alignments, leaf_names)
+    states, offsets = load_alignments(alignments, leaf_names, workers)
     L = len(alignments)
     if pi is None:
         hist = eng.state_histogram(states, offsets, device=device)
@@ -90,19 +132,30 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     culled = np.where(out["nres"] >= threshold, corrected, np.nan)
     per_locus = []
     for l, a in enumerate(alignments):
-        sl = slice(offsets[l], offsets[l + 1])
-        r = culled[sl]
+        r = culled[offsets[l]:offsets[l + 1]]
         base = os.path.basename(a)
         if base in subsets:
             r = r[subsets[base][0]:subsets[base][1]]
         per_locus.append(r)
-        if output_dir is not None:
-            n = offsets[l + 1] - offsets[l]
-            doc = format_rates_json(pi[l], exch[l], np.arange(1, n + 1), out["subst"][sl], rate4[sl], out["lnl"][sl],
-                                    corrected[sl])
-            with open(os.path.join(output_dir, base + ".rates"), "w") as fh:
-                json.dump(doc, fh, indent=4)
-        if progress:
+    if output_dir is not None:
+        global _WRITE_CTX
+        _WRITE_CTX = (alignments, offsets, pi, exch, out["subst"], rate4, out["lnl"], corrected, output_dir)
+        if workers > 1 and L > 1:
+            import multiprocessing
+            # forked AFTER the results exist: the children inherit the arrays, only format text and write
+            # files, and never touch the GPU runtime
+            with multiprocessing.get_context("fork").Pool(workers) as pool:
+                for _ in pool.imap_unordered(_write_one, range(L), chunksize=max(1, L // (8 * workers))):
+                    if progress:
+                        progress()
+        else:
+            for l in range(L):
+                _write_one(l)
+                if progress:
+                    progress()
+        _WRITE_CTX = None
+    elif progress:
+        for _ in alignments:
             progress()
     if need_subset:
         tables = _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode)

@@ -153,3 +153,30 @@ def plan_inputs(root, names):
     factor = correction_factor(root)
     parent, blen, leaf = newick.to_arrays(root, names)
     return dict(depth=depth, T=int(depth), correction=factor, parent=parent, blen=blen / factor, leaf=leaf)
+
+
+_CODE2CHAR = {1: "A", 2: "C", 4: "G", 8: "T", 15: "-", 5: "R", 10: "Y", 6: "S", 9: "W", 12: "K", 3: "M",
+              14: "B", 13: "D", 11: "H", 7: "V"}
+
+
+def write_nexus_dir(directory, states, locus_offsets, names, root, prefix="locus"):
+    """Write a simulated batch as tapir's input: one NEXUS alignment per locus plus `tree.newick`
+    (used by end-to-end tests and the ingest/egress timing)."""
+    import os
+    lut = np.zeros(16, dtype="S1")
+    for k, v in _CODE2CHAR.items():
+        lut[k] = v.encode()
+    states = np.asarray(states)
+    chars = lut[states]  # [ntaxa, ncols] bytes
+    for l in range(len(locus_offsets) - 1):
+        a, b = int(locus_offsets[l]), int(locus_offsets[l + 1])
+        with open(os.path.join(directory, "%s%05d.nex" % (prefix, l)), "w") as fh:
+            fh.write("#NEXUS\nbegin data;\n\tdimensions ntax=%d nchar=%d;\n\tformat datatype=dna missing=? gap=-;\nmatrix\n"
+                     % (len(names), b - a))
+            for t, nm in enumerate(names):
+                fh.write("%s %s\n" % (nm, chars[t, a:b].tobytes().decode()))
+            fh.write(";\nend;\n")
+    tree_path = os.path.join(directory, "tree.newick")
+    with open(tree_path, "w") as fh:
+        fh.write(newick.write(root) + "\n")
+    return tree_path

@@ -375,3 +375,50 @@ def test_sharded_tables_gloo_world2(tmp_path):
                               [10, 30], [[5, 15]], correction=pin["correction"])
     full = plan.run_fused(d["states"].numpy())["tables"]
     assert np.array_equal(a, full)  # bit-identical: a locus' row does not depend on the sharding
+
+
+def test_fast_rates_writer_is_byte_identical_to_json_dump():
+    """pipeline.dumps_rates_json must equal json.dumps(format_rates_json(...), indent=4): that is the text
+    tapir leaves on disk after parse_site_rates rewrote HyPhy's file (tapir/compute.py:43)."""
+    from tapir_amd import pipeline
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 7, 500):
+        subst = rng.gamma(1, 1, n) * rng.choice([0, 1, 1e-5, 10, 1234.5], n)
+        rate = rng.gamma(1, 0.3, n) * rng.choice([0, 1, 1e-6], n)
+        ll = -rng.gamma(2, 3, n)
+        ll[:n // 7] = -0.00001  # rounds to -0.0
+        pi = rng.dirichlet([5] * 4)
+        ex = [0.96, 1.0, 0.58, 0.36, 1.87, 0.51]
+        site = np.arange(1, n + 1)
+        a = json.dumps(pipeline.format_rates_json(pi, ex, site, subst, rate, ll, rate / 100), indent=4)
+        assert pipeline.dumps_rates_json(pi, ex, site, subst, rate, ll, rate / 100) == a
+        assert json.loads(a)["sites"]["freqs"]["A"] == float(pi[0])
+
+
+def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, oracle):
+    """--multiprocessing (reference: Pool(cpu_count()-1), bin/tapir_compute.py:159-164) parallelises only the
+    host side; every output file must be identical to the sequential run."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    from tapir_amd import cli, synth
+    d = synth.simulate(6, 40, 5, 3)
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    tree = synth.write_nexus_dir(str(aln), d["states"].numpy(), d["locus_offsets"], d["names"], d["root"])
+    shutil.move(tree, tmp_path / "tree.newick")
+    outs = []
+    for flag in ([], ["--multiprocessing"]):
+        out = tmp_path / ("out" + str(len(outs)))
+        out.mkdir()
+        cli.main([str(aln), str(tmp_path / "tree.newick"), "--output", str(out), "--times", "10,30", "--intervals", "5-15",
+                  "--exchangeabilities", "1,1.2,0.8,0.9,1.5,1"] + flag, engine_mod=oracle_engine)
+        outs.append(out)
+    names = sorted(os.listdir(outs[0]))
+    assert names == sorted(os.listdir(outs[1])) and len(names) == 8
+    for n in names:
+        if n.endswith(".rates") or n.endswith(".newick"):
+            assert open(outs[0] / n).read() == open(outs[1] / n).read(), n
+    q = "select l.locus, n.time, n.pi from loci l join net n on n.id = l.id order by 1, 2"
+    a = sqlite3.connect(outs[0] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
+    b = sqlite3.connect(outs[1] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
+    assert a == b and len(a) == 6 * 100
