@@ -133,7 +133,7 @@ def main(argv=None, engine_mod=None):
     workers = 1
     if args.multiprocessing:  # the reference: Pool(processes = cpu_count() - 1), bin/tapir_compute.py:162-163
         from multiprocessing import cpu_count
-        workers = max(1, cpu_count() - 1)
+        workers = max(1, min(16, cpu_count() - 1))  # forking hundreds of workers costs more than it saves
     if not args.site_rates:
         print("\nEstimating site rates and PI for files:")
         alignments = base.get_files(args.alignments, '*.nex,*.nexus')
