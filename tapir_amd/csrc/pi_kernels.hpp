@@ -251,7 +251,9 @@ __global__ __launch_bounds__(kPiBlock) void pi_partial_kernel(PiParams P) {
         for (int j = 0; j < kPiColsPerThread; ++j) {
             if (!ok[j]) continue;
             double res, err = 0.0;
-            if (P.integ_mode == TPHIP_INTEG_QUADPACK) quad_townsend(a, b, r[j], res, err);
+            // (measured: the table-driven exp of fast_exp.hpp makes this kernel 1.65x SLOWER -- 84 scattered LDS
+            //  reads per column from one table shared by 256 threads -- so the quadrature keeps the library exp)
+            if (P.integ_mode == TPHIP_INTEG_QUADPACK) quad_townsend<false>(a, b, r[j], nullptr, res, err);
             else res = integral_closed(a, b, r[j]);
             si += res;
             se += err;
@@ -292,7 +294,7 @@ __global__ void townsend_dense_kernel(const double* __restrict__ rates, int64_t 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double r = rates[i];
-    for (int k = 0; k < n_times; ++k) out[(size_t)k * n + i] = townsend_pi(times[k], r);
+    for (int k = 0; k < n_times; ++k) out[(size_t)k * n + i] = townsend_pi<false>(times[k], r, nullptr);
 }
 
 // tapir/compute.py:50-52 vectorised over sites (what numpy.vectorize(get_integral_over_times) returns)
@@ -304,7 +306,7 @@ __global__ void quad_sites_kernel(const double* __restrict__ rates, int64_t n, d
     double res = __longlong_as_double(0x7ff8000000000000ll), err = res;
     if (isfinite(r)) {
         err = 0.0;
-        if (integ_mode == TPHIP_INTEG_QUADPACK) quad_townsend(a, b, r, res, err);
+        if (integ_mode == TPHIP_INTEG_QUADPACK) quad_townsend<false>(a, b, r, nullptr, res, err);
         else res = integral_closed(a, b, r);
     }
     integral[i] = res;

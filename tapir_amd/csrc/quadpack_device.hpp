@@ -10,15 +10,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include "fast_exp.hpp"
 
 namespace tphip {
 
 // Townsend 2007 eq. 10 as coded in tapir/compute.py:46-48, same operation order.
 // (no FMA contraction anywhere in this file: QUADPACK's roundings are part of the behaviour being emulated;
 //  a fused `centr - hlgth*xgk` moves an abscissa by 1 ulp, which a sharply peaked integrand amplifies.)
-__device__ __forceinline__ double townsend_pi(double t, double r) {
+// TAB: exp through the 64-entry LDS table of fast_exp.hpp (<= 1.5 ulp; arguments are never positive because
+// rates and times are non-negative) instead of the math library's exp -- the GK21 rule is 21 exps per panel.
+template <bool TAB>
+__device__ __forceinline__ double townsend_pi(double t, double r, const double* __restrict__ etab) {
 #pragma clang fp contract(off)
-    return 16.0 * (r * r) * t * exp(-(4.0 * r * t));
+    const double x = -(4.0 * r * t);
+    if constexpr (TAB) return 16.0 * (r * r) * t * exp_nonpos_tab(fmin(x, 0.0), etab);
+    else return 16.0 * (r * r) * t * exp(x);
 }
 
 struct GK21 {
@@ -41,20 +47,21 @@ __device__ __constant__ const double kWg[5] = {
 
 // QUADPACK dqk21 on [a,b] for f(t) = townsend_pi(t, rate).  The Kronrod sum runs in QUADPACK's order
 // (centre, the five Gauss abscissae, then the five Kronrod-only ones) so the result rounds as scipy's does.
-__device__ __forceinline__ GK21 dqk21(double rate, double a, double b) {
+template <bool TAB>
+__device__ __forceinline__ GK21 dqk21(double rate, double a, double b, const double* __restrict__ etab) {
 #pragma clang fp contract(off)
     const double epmach = DBL_EPSILON, uflow = DBL_MIN;
     double fv1[10], fv2[10];
     const double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
     double resg = 0.0;
-    const double fc = townsend_pi(centr, rate);
+    const double fc = townsend_pi<TAB>(centr, rate, etab);
     double resk = kWgk[10] * fc;
     double resabs = fabs(resk);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int jtw = 2 * j + 1;
         const double absc = hlgth * kXgk[jtw];
-        const double f1 = townsend_pi(centr - absc, rate), f2 = townsend_pi(centr + absc, rate);
+        const double f1 = townsend_pi<TAB>(centr - absc, rate, etab), f2 = townsend_pi<TAB>(centr + absc, rate, etab);
         fv1[jtw] = f1; fv2[jtw] = f2;
         const double fsum = f1 + f2;
         resg += kWg[j] * fsum;
@@ -65,7 +72,7 @@ __device__ __forceinline__ GK21 dqk21(double rate, double a, double b) {
     for (int j = 0; j < 5; ++j) {
         const int jtwm1 = 2 * j;
         const double absc = hlgth * kXgk[jtwm1];
-        const double f1 = townsend_pi(centr - absc, rate), f2 = townsend_pi(centr + absc, rate);
+        const double f1 = townsend_pi<TAB>(centr - absc, rate, etab), f2 = townsend_pi<TAB>(centr + absc, rate, etab);
         fv1[jtwm1] = f1; fv2[jtwm1] = f2;
         const double fsum = f1 + f2;
         resk += kWgk[jtwm1] * fsum;
@@ -194,8 +201,9 @@ __device__ inline void dqelg(int* n, double* epstab, double* result, double* abs
 }
 
 // The adaptive part of dqagse, entered only when the first panel is not accepted.
-__device__ __noinline__ void dqagse_adaptive(double rate, double a, double b, const GK21 first, double* result_out,
-                                             double* abserr_out) {
+template <bool TAB>
+__device__ __noinline__ void dqagse_adaptive(double rate, double a, double b, const GK21 first, const double* __restrict__ etab,
+                                             double* result_out, double* abserr_out) {
 #pragma clang fp contract(off)
     constexpr int LIMIT = 50;
     const double epsabs = 1.49e-8, epsrel = 1.49e-8;
@@ -220,7 +228,7 @@ __device__ __noinline__ void dqagse_adaptive(double rate, double a, double b, co
     for (last = 2; last <= LIMIT; ++last) {
         const double a1 = alist[maxerr], b1 = 0.5 * (alist[maxerr] + blist[maxerr]), a2 = b1, b2 = blist[maxerr];
         const double erlast = errmax;
-        const GK21 g1 = dqk21(rate, a1, b1), g2 = dqk21(rate, a2, b2);
+        const GK21 g1 = dqk21<TAB>(rate, a1, b1, etab), g2 = dqk21<TAB>(rate, a2, b2, etab);
         const double area1 = g1.result, area2 = g2.result, error1 = g1.abserr, error2 = g2.abserr;
         const double area12 = area1 + area2, erro12 = error1 + error2;
         errsum = errsum + erro12 - errmax;
@@ -326,16 +334,18 @@ __device__ __noinline__ void dqagse_adaptive(double rate, double a, double b, co
 }
 
 // scipy.integrate.quad(get_townsend_pi, a, b, args=(rate)) -> (integral, abserr)
-__device__ __forceinline__ void quad_townsend(double a, double b, double rate, double& result, double& abserr) {
+template <bool TAB>
+__device__ __forceinline__ void quad_townsend(double a, double b, double rate, const double* __restrict__ etab, double& result,
+                                              double& abserr) {
 #pragma clang fp contract(off)
     const double epsabs = 1.49e-8, epsrel = 1.49e-8, epmach = DBL_EPSILON;
-    const GK21 g = dqk21(rate, a, b);
+    const GK21 g = dqk21<TAB>(rate, a, b, etab);
     result = g.result;
     abserr = g.abserr;
     const double errbnd = fmax(epsabs, epsrel * fabs(g.result));
     const bool roundoff = (g.abserr <= 100.0 * epmach * g.resabs && g.abserr > errbnd);  // ier = 2
     const bool accept = roundoff || (g.abserr <= errbnd && g.abserr != g.resasc) || g.abserr == 0.0;
-    if (!accept) dqagse_adaptive(rate, a, b, g, &result, &abserr);
+    if (!accept) dqagse_adaptive<TAB>(rate, a, b, g, etab, &result, &abserr);
 }
 
 // Closed form: int_a^b 16 r^2 t exp(-4 r t) dt = g(4rb) - g(4ra), g(x) = 1 - (1+x) exp(-x); series for small x.
