@@ -40,7 +40,7 @@ def _run(torch, plan, d_states, nloci):
     return out
 
 
-@pytest.mark.parametrize("workload,nloci", [("C3", 20), ("C2", 1000)])
+@pytest.mark.parametrize("workload,nloci", [("C3", 20), ("C2", 1000), ("C4", 300), ("C5", 6)])
 def test_fullsize_properties(workload, nloci, oracle):
     torch, engine, d, pin, ncols, ntaxa, times, intervals = _setup(workload, nloci)
     plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"],
