@@ -385,8 +385,11 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* __rest
 // end of its share.  Equal column counts balance the waves to ~2 % (thousands of columns per wave), so there
 // is neither a partially filled last round of workgroups nor a tail of short slices.  No wave waits on
 // another: every wave leaves after its own share, whatever the others do.
+#ifndef TPHIP_SITE_MIN_WAVES
+#define TPHIP_SITE_MIN_WAVES 1
+#endif
 template <int NW>
-__global__ __launch_bounds__(kSiteBlock) void site_rate_kernel(SiteParams P) {
+__global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_kernel(SiteParams P) {
     extern __shared__ double lds[];
     double* wtab = lds;          // [16 masks][4]
     double* mtab = lds + 64;     // [32] the locus' model
