@@ -201,6 +201,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 __global__ __launch_bounds__(kPiBlock) void pi_partial_kernel(PiParams P) {
     __shared__ double red[kTimeTile][4];
+    // per-tile transpose buffer: [time][16 segments of 16 threads, each padded to 17 doubles]
+    __shared__ double tile[kTimeTile][16 * 17];
     const int chunk = blockIdx.x;
     const int locus = P.chunk_locus[chunk];
     const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
@@ -233,14 +235,27 @@ __global__ __launch_bounds__(kPiBlock) void pi_partial_kernel(PiParams P) {
                 p *= q;
             }
         }
+        // Sum over the 256 threads WITHOUT 16 butterfly reductions (96 cross-lane FP64 exchanges per wave cost ten
+        // times the arithmetic above): transpose through LDS, each thread then adds one 16-value segment of one
+        // time point in a fixed order, and a 4-step exchange inside 16-lane groups finishes the sum.
+        {
+            const int slot = (threadIdx.x >> 4) * 17 + (threadIdx.x & 15);
 #pragma unroll
-        for (int i = 0; i < kTimeTile; ++i) {
-            const double s = wave_sum(acc[i]);
-            if (lane == 0) red[i][wave] = s;
+            for (int i = 0; i < kTimeTile; ++i) tile[i][slot] = acc[i];
         }
         __syncthreads();
-        if (threadIdx.x < kTimeTile && t0 + threadIdx.x < P.T)
-            out[t0 + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+        {
+            const int i = threadIdx.x >> 4, seg = threadIdx.x & 15;
+            const double* src = &tile[i][seg * 17];
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += src[k];
+            sum += __shfl_xor(sum, 8);
+            sum += __shfl_xor(sum, 4);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 1);
+            if (seg == 0 && t0 + i < P.T) out[t0 + i] = sum;
+        }
         __syncthreads();
     }
     // ---- interval integrals
