@@ -1,6 +1,6 @@
 # end-to-end CLI timing on a synthetic directory of NEXUS files (ingest + engine + JSON + sqlite)
 import os, sys, time, tempfile, shutil, cProfile, pstats
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tapir_amd import synth, cli
 nloci, ncols, ntaxa = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

@@ -1,6 +1,6 @@
 # PCIe-inclusive rate: host-pointer tphip_run_fused on the C3 shape (numpy in, numpy out)
-import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tapir_amd import engine, synth
 nloci, ncols, ntaxa, times, intervals = synth.WORKLOADS["C3"]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc.sh <tag> [bench args...]   (run on the GPU box from the repo root)
+# usage: tools/pmc.sh <tag> [bench args...]   (run on the GPU box from the repo root)
 set -u
 TAG=$1; shift
 export TMPDIR=/tmp
