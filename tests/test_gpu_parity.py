@@ -341,3 +341,58 @@ def test_hyphy_protocol_shim(golden_dir, tmp_path, oracle):
     p = subprocess.run([sys.executable, os.path.join(root, "bin", "tphip_hyphy"), "x.bf"], input="nope.nex\n%s\n%s" % (tree, out),
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.stdout.startswith("Error")
+
+
+def _random_states(rng, ntaxa, ncols, ambig=0.15, gaps=0.1):
+    base = (1 << rng.integers(0, 4, size=(ntaxa, ncols))).astype(np.uint8)
+    # low-rate columns: copy a single base down most of the column
+    const = rng.random(ncols) < 0.4
+    base[:, const] = base[0, const]
+    amb = rng.random((ntaxa, ncols)) < ambig
+    base[amb] = rng.integers(1, 16, size=int(amb.sum())).astype(np.uint8)  # any IUPAC union, incl. N = 15
+    base[rng.random((ntaxa, ncols)) < gaps] = 15
+    return base
+
+
+@pytest.mark.parametrize("newick_text", [
+    "((a:0.3,b:0.1,c:0.2,d:0.05):0.2,(e:0.4,f:0.0):0.1,g:0.3);",                       # polytomies, trifurcating root, zero branch
+    "(((((((a:.1,b:.2):.1,c:.3):.1,d:.2):.1,e:.1):.2,f:.3):.1,g:.2):.1,h:.4);",          # caterpillar: stack depth 0
+    "(((a:.1,b:.2):.3,(c:.1,d:.2):.2):.1,((e:.3,f:.1):.2,(g:.2,h:.1):.3):.2);",          # balanced: deepest stack
+    "((a:0.2,b:0.3):0.0,(c:0.1,(d:0.2,e:0.3):0.4)x:0.2)root;",                           # internal labels, zero internal branch
+])
+def test_tree_shapes_and_ambiguity_codes(oracle, newick_text):
+    """Multifurcations, zero-length branches, unrooted (trifurcating) roots and IUPAC ambiguity masks: the
+    tree compiler + kernel against the oracle's plain post-order recursion."""
+    engine = _engine()
+    from tapir_amd import newick
+    root = newick.parse(newick_text)
+    names = [n.name for n in newick.leaves(root)]
+    parent, blen, leaf = newick.to_arrays(root, names)
+    rng = np.random.default_rng(len(newick_text))
+    ncols = 700
+    st = _random_states(rng, len(names), ncols)
+    pi = np.array([0.31, 0.19, 0.23, 0.27])
+    ex = np.array([1.3, 1.0, 0.6, 0.8, 2.1, 0.9])
+    plan = engine.Plan(len(names), parent, blen, leaf, [0, ncols], [pi], [ex], 3, [1], [[0, 2]], threshold=2)
+    got = plan.site_rates(st)
+    ref = oracle.site_rates(st, parent, blen, leaf, pi, ex)
+    assert np.array_equal(got["flag"], ref["flag"])
+    assert np.array_equal(got["nres"], ref["nres"])
+    kappa = plan.models()[3]
+    pin = dict(parent=parent, blen=blen, leaf=leaf)
+    _assert_rates_match(oracle, got, ref, slice(0, ncols), st, pin, pi, ex, kappa[0])
+    assert np.abs(got["lnl"] - ref["lnl"]).max() < 1e-10 * max(1.0, np.abs(ref["lnl"]).max())
+    # the diagnostic (byte path) agrees with the oracle's curve everywhere, also on flat / ambiguous columns
+    u = rng.uniform(-2, 2, ncols)
+    f, g, h = plan.eval_columns(st, u)
+    for c in range(0, ncols, 37):
+        fo, go, ho = oracle.column_curve(st, parent, blen, leaf, pi, ex, c, np.array([u[c]]))
+        assert abs(f[c] - fo[0]) < 1e-11 * max(1, abs(fo[0])) and abs(g[c] - go[0]) < 1e-10 and abs(h[c] - ho[0]) < 1e-10
+    plan.close()
+
+
+def test_plan_rejects_tree_alignment_mismatch(chr1_918):
+    engine = _engine()
+    c = chr1_918
+    with pytest.raises(engine.TphipError, match="number of leaves"):
+        engine.Plan(6, c["parent"], c["blen"], c["leaf"], [0, 10], [c["pi"]], [c["exch"]], 10, [1], [[0, 1]])
