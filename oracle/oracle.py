@@ -25,6 +25,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 _c_dp = ctypes.POINTER(ctypes.c_double)
+_dp_t = _c_dp
 _c_u8p = ctypes.POINTER(ctypes.c_uint8)
 _c_i32p = ctypes.POINTER(ctypes.c_int32)
 
@@ -60,6 +61,8 @@ def lib():
                                        _c_dp, _c_dp, ctypes.c_int64, _c_dp, ctypes.c_int32, _c_dp, _c_dp, _c_dp]
         L.orc_gtr_eigen.restype = None
         L.orc_gtr_eigen.argtypes = [_c_dp] * 6
+        L.orc_locus_loglik.restype = ctypes.c_double
+        L.orc_locus_loglik.argtypes = [_c_u8p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, _c_i32p, _dp_t, _c_i32p, _dp_t, _dp_t]
         L.orc_informative_counts.restype = None
         L.orc_informative_counts.argtypes = [_c_u8p, ctypes.c_int64, ctypes.c_int32, _c_i32p]
         _LIB = L
@@ -290,6 +293,19 @@ def column_curve(states, parent, blen, leaf_taxon, pi, exch, col, u):
                            _dp(blen), leaf_taxon.ctypes.data_as(_c_i32p), _dp(pi), _dp(exch), col, _dp(u), len(u),
                            _dp(f), _dp(g), _dp(h))
     return f, g, h
+
+
+def locus_loglik(states, parent, blen, leaf_taxon, pi, exch):
+    """HyPhy stage-1 objective: sum over columns of log L at site rate 1 (models_and_rates.bf:487-520)."""
+    states = np.ascontiguousarray(states, dtype=np.uint8)
+    ntaxa, ncols = states.shape
+    parent = np.ascontiguousarray(parent, dtype=np.int32)
+    blen = np.ascontiguousarray(blen, dtype=np.float64)
+    leaf_taxon = np.ascontiguousarray(leaf_taxon, dtype=np.int32)
+    pi = np.ascontiguousarray(pi, dtype=np.float64)
+    exch = np.ascontiguousarray(exch, dtype=np.float64)
+    return lib().orc_locus_loglik(states.ctypes.data_as(_c_u8p), ncols, ntaxa, len(parent), parent.ctypes.data_as(_c_i32p),
+                                  _dp(blen), leaf_taxon.ctypes.data_as(_c_i32p), _dp(pi), _dp(exch))
 
 
 def gtr_eigen(pi, exch):

@@ -732,3 +732,20 @@ void orc_informative_counts(const uint8_t *states, int64_t ncols, int32_t ntaxa,
         counts[c] = k;
     }
 }
+
+/* HyPhy stage 1 objective (bf:487-520, 647-655): sum over columns of log L with every site at rate 1,
+ * for given exchangeabilities and branch lengths (plain post-order recursion, one column at a time). */
+double orc_locus_loglik(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                        const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch) {
+    orc_model m;
+    orc_tree tr = {nnodes, ntaxa, parent, leaf_taxon, blen, NULL};
+    double total = 0.0, f, g, h;
+    build_model(pi, exch, &m);
+    tr.part = (double *)malloc(sizeof(double) * 12 * (size_t)nnodes);
+    for (int64_t c = 0; c < ncols; ++c) {
+        column_loglik(&m, &tr, states, ncols, c, 0.0, &f, &g, &h);
+        total += f;
+    }
+    free(tr.part);
+    return total;
+}

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "gtr_model.hpp"
+#include "locus_lik_kernel.hpp"
 #include "pi_kernels.hpp"
 #include "site_rate_kernel.hpp"
 #include "tphip.h"
@@ -84,7 +85,8 @@ struct tphip_plan {
     DevBuf<TreeOp> d_ops;
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
-    DevBuf<int32_t> d_tip_taxon;
+    DevBuf<int32_t> d_tip_taxon, d_op_node;
+    int32_t nnodes = 0;
     int32_t nwords = 0;
     DevBuf<int32_t> d_site_chunk_locus, d_site_chunk_index, d_pi_chunk_locus, d_pi_chunk_index, d_times, d_intervals;
     DevBuf<unsigned long long> d_evals;
@@ -118,7 +120,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_ops.release(); plan->d_models.release(); plan->d_offsets.release();
     plan->d_locus_pichunk_offsets.release(); plan->d_site_chunk_locus.release(); plan->d_site_chunk_index.release();
     plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
-    plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release();
+    plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TPHIP_OK;
@@ -201,6 +203,8 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     for (const TreeOp& op : p->prog.ops) if (op.code <= OP_TIP_MUL) tip_taxon.push_back(op.taxon);
     p->nwords = (int32_t)((tip_taxon.size() + 7) / 8);
     if (e == hipSuccess) e = p->d_tip_taxon.upload(tip_taxon);
+    if (e == hipSuccess) e = p->d_op_node.upload(p->prog.op_node);
+    p->nnodes = d->nnodes;
     if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
     if (e == hipSuccess) e = p->d_offsets.upload(p->h_offsets);
     if (e == hipSuccess) e = p->d_locus_pichunk_offsets.upload(lpo);
@@ -480,6 +484,30 @@ int tphip_quad_townsend_dev(int32_t device, const double* d_rates, int64_t n, do
     return TPHIP_OK;
 }
 
+int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand, const int32_t* d_cand_locus,
+                           const double* d_cand_exch, const double* d_cand_blen, double* d_out, void* stream) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (ncand < 0 || (ncand && (!d_states || !d_cand_locus || !d_cand_exch || !d_cand_blen || !d_out)))
+        return fail(TPHIP_ERR_INVALID, "null device pointer");
+    if (ncand == 0) return TPHIP_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    LikParams L;
+    L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;
+    L.ops = p->d_ops.p; L.op_node = p->d_op_node.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes;
+    L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch; L.cand_blen = d_cand_blen;
+    L.out = d_out;
+    const size_t lds = ((size_t)p->nnodes * 16 + (size_t)p->prog.stack_depth * 4 * kLikBlock) * sizeof(double);
+    if (lds > 150 * 1024) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-likelihood kernel's LDS tables");
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    locus_loglik_kernel<<<dim3((unsigned)ncand), dim3(kLikBlock), lds, (hipStream_t)stream>>>(L);
+    HIP_TRY(hipGetLastError());
+    return TPHIP_OK;
+}
+
 int tphip_state_histogram_dev(int32_t device, const uint8_t* d_states, int64_t ncols_total, int32_t ntaxa,
                               const int64_t* d_locus_offsets, int64_t nloci, int64_t* d_hist, void* stream) {
     if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
@@ -629,6 +657,49 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     HIP_TRY(hipMemcpy(f, d_f, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(g, d_g, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h, d_h, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
+}
+
+int tphip_free_device(tphip_plan* p, void* d_ptr) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return TPHIP_OK;
+}
+
+int tphip_locus_loglik(tphip_plan* p, const uint8_t* states, void** d_states_cache, int64_t ncand, const int32_t* cand_locus,
+                       const double* cand_exch, const double* cand_blen, double* out) {
+    if (!p || !states || ncand < 0 || (ncand && (!cand_locus || !cand_exch || !cand_blen || !out)))
+        return fail(TPHIP_ERR_INVALID, "null argument");
+    if (ncand == 0) return TPHIP_OK;
+    for (int64_t c = 0; c < ncand; ++c)
+        if (cand_locus[c] < 0 || cand_locus[c] >= p->nloci) return fail(TPHIP_ERR_INVALID, "cand_locus out of range");
+    HIP_TRY(hipSetDevice(p->device));
+    Scratch S;
+    const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
+    uint8_t* d_s = d_states_cache ? (uint8_t*)*d_states_cache : nullptr;
+    if (!d_s) {
+        if (d_states_cache) {
+            HIP_TRY(hipMalloc((void**)&d_s, nb ? nb : 1));
+            *d_states_cache = d_s;
+        } else {
+            d_s = S.get<uint8_t>(nb);
+            if (!d_s) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+        }
+        HIP_TRY(hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice));
+    }
+    int32_t* d_l = S.get<int32_t>((size_t)ncand);
+    double* d_e = S.get<double>((size_t)ncand * 6);
+    double* d_b = S.get<double>((size_t)ncand * (size_t)p->nnodes);
+    double* d_o = S.get<double>((size_t)ncand);
+    if (!d_l || !d_e || !d_b || !d_o) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_l, cand_locus, sizeof(int32_t) * (size_t)ncand, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_e, cand_exch, sizeof(double) * (size_t)ncand * 6, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b, cand_blen, sizeof(double) * (size_t)ncand * (size_t)p->nnodes, hipMemcpyHostToDevice));
+    int rc = tphip_locus_loglik_dev(p, d_s, ncand, d_l, d_e, d_b, d_o, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * (size_t)ncand, hipMemcpyDeviceToHost));
     return TPHIP_OK;
 }
 

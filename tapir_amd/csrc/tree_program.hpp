@@ -34,6 +34,7 @@ static_assert(sizeof(TreeOp) == 16, "TreeOp is read with one s_load_dwordx4");
 
 struct TreeProgram {
     std::vector<TreeOp> ops;
+    std::vector<int32_t> op_node;  // tree node whose branch a TIP_* / BRANCH op climbs (-1 for PUSH / POP_MUL)
     int32_t stack_depth = 0;   // LDS slots per lane
     double chrono_length = 0;  // sum of all branch lengths (bf:1006-1013)
     int32_t nleaves = 0;
@@ -91,6 +92,7 @@ inline std::string build_tree_program(int32_t ntaxa, int32_t nnodes, const int32
     }
     out->stack_depth = need[root] - 1;
     out->ops.clear();
+    out->op_node.clear();
     // iterative emit (explicit stack: trees can be deep caterpillars)
     struct Frame { int32_t node; size_t next; };
     std::vector<Frame> st;
@@ -104,8 +106,9 @@ inline std::string build_tree_program(int32_t ntaxa, int32_t nnodes, const int32
             ++f.next;
             if (kids[c].empty()) {
                 out->ops.push_back({first ? OP_TIP_SET : OP_TIP_MUL, leaf_taxon[c], blen[c]});
+                out->op_node.push_back(c);
             } else {
-                if (!first) out->ops.push_back({OP_PUSH, 0, 0.0});
+                if (!first) { out->ops.push_back({OP_PUSH, 0, 0.0}); out->op_node.push_back(-1); }
                 st.push_back({c, 0});
             }
         } else {
@@ -113,8 +116,9 @@ inline std::string build_tree_program(int32_t ntaxa, int32_t nnodes, const int32
             if (!st.empty()) {
                 // finished internal child n of st.back(): climb its branch, then merge with a parked sibling
                 out->ops.push_back({OP_BRANCH, 0, blen[n]});
+                out->op_node.push_back(n);
                 bool was_first = (st.back().next == 1);
-                if (!was_first) out->ops.push_back({OP_POP_MUL, 0, 0.0});
+                if (!was_first) { out->ops.push_back({OP_POP_MUL, 0, 0.0}); out->op_node.push_back(-1); }
             }
         }
     }

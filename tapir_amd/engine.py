@@ -50,6 +50,7 @@ SYMBOLS = [
     ("tphip_run_dev", ctypes.c_int, [_vp] * 9 + [ctypes.c_size_t, _vp]),
     ("tphip_townsend_pi_dense_dev", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     ("tphip_quad_townsend_dev", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp, _vp]),
+    ("tphip_locus_loglik_dev", ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     ("tphip_state_histogram_dev", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     ("tphip_profile_enable", ctypes.c_int, [_vp, _i32]),
     ("tphip_profile_read", ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_f64), ctypes.POINTER(_i64), _i32]),
@@ -61,6 +62,8 @@ SYMBOLS = [
     ("tphip_quad_townsend", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp]),
     ("tphip_state_histogram", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     ("tphip_eval_columns", ctypes.c_int, [_vp] * 6),
+    ("tphip_locus_loglik", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _vp, _vp, _vp]),
+    ("tphip_free_device", ctypes.c_int, [_vp, _vp]),
 ]
 
 _lib = None
@@ -200,6 +203,23 @@ class Plan:
                                             h.ctypes.data))
         return f, g, h
 
+    def locus_loglik(self, states, cand_locus, cand_exch, cand_blen, cache=None):
+        """Sum over columns of log L for candidate (locus, exchangeabilities[6], branch lengths[nnodes]) sets.
+        cache: a one-element list holding the device copy of `states` between calls (see StatesOnDevice)."""
+        states = _np(states, np.uint8)
+        cl = _np(cand_locus, np.int32).reshape(-1)
+        ce = _np(cand_exch, np.float64).reshape(len(cl), 6)
+        cb = _np(cand_blen, np.float64).reshape(len(cl), -1)
+        out = np.empty(len(cl))
+        ref = ctypes.byref(cache.ptr) if cache is not None else None
+        _check(self._lib.tphip_locus_loglik(self._h, states.ctypes.data, ref, len(cl), cl.ctypes.data, ce.ctypes.data,
+                                            cb.ctypes.data, out.ctypes.data))
+        return out
+
+    def device_cache(self):
+        """Holder that keeps the alignment on the device across locus_loglik calls; release() frees it."""
+        return _DeviceCache(self)
+
     def models(self):
         L = self.nloci
         lam, U, Ui, kappa = np.empty((L, 4)), np.empty((L, 4, 4)), np.empty((L, 4, 4)), np.empty(L)
@@ -233,6 +253,16 @@ class Plan:
         n = _i64()
         _check(self._lib.tphip_last_eval_count(self._h, ctypes.byref(n)))
         return n.value
+
+
+class _DeviceCache:
+    def __init__(self, plan):
+        self.plan, self.ptr = plan, _vp()
+
+    def release(self):
+        if self.ptr:
+            _check(self.plan._lib.tphip_free_device(self.plan._h, self.ptr))
+            self.ptr = _vp()
 
 
 def state_histogram(states, locus_offsets, device=0):
