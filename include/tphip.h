@@ -160,12 +160,16 @@ int tphip_state_histogram_dev(int32_t device, const uint8_t *d_states, int64_t n
 
 /* Whole-locus log-likelihood for a batch of candidate parameter sets: the objective HyPhy's stage 1 maximises in
  * every `Optimize(lf_MLES, lf)` (models_and_rates.bf:487-520, 647-655): sum over the columns of locus
- * cand_locus[c] of log L(column | exchangeabilities cand_exch[c][6] = AC,AG,AT,CG,CT,GT, branch lengths
- * cand_blen[c][nnodes] above each node (post-order node numbering of the plan's tree; the root's entry is
- * ignored), base frequencies = the plan's pi for that locus), every site at rate 1.  One workgroup per
- * candidate; the optimiser itself runs on the host (tapir_amd/stage1.py). */
+ * cand_locus[c] of log L(column | exchangeabilities cand_exch[c][6] = AC,AG,AT,CG,CT,GT, branch lengths, base
+ * frequencies = the plan's pi for that locus), every site at rate 1.  Branch lengths (above each node, post-order
+ * numbering of the plan's tree, root entry ignored) of candidate c are
+ *     blen_vecs[cand_vec[c]][b] * cand_scale[c] * (b == cand_pidx[c] ? cand_pfac[c] : 1)
+ * so a finite-difference stencil, or the rate-class models that only rescale stashed lengths (bf:613-619), share
+ * one stored vector.  One workgroup per candidate; the optimiser runs on the host (tapir_amd/stage1.py). */
 int tphip_locus_loglik_dev(tphip_plan *plan, const uint8_t *d_states, int64_t ncand, const int32_t *d_cand_locus,
-                           const double *d_cand_exch, const double *d_cand_blen, double *d_out, void *stream);
+                           const double *d_cand_exch, const double *d_blen_vecs, const int32_t *d_cand_vec,
+                           const double *d_cand_scale, const int32_t *d_cand_pidx, const double *d_cand_pfac,
+                           double *d_out, void *stream);
 
 /* Profiling hooks for bench.py: when enabled the library brackets its dominant kernel (site rates) with
  * HIP events on the caller's stream and accumulates the elapsed time. */
@@ -192,8 +196,10 @@ int tphip_state_histogram(int32_t device, const uint8_t *states, int64_t ncols_t
 /* host-pointer twin of tphip_locus_loglik_dev; d_states_cache may keep the alignment on the device between calls:
  * pass the address of a NULL void* the first time and free it with tphip_free_device when done (NULL = copy the
  * alignment on every call) */
-int tphip_locus_loglik(tphip_plan *plan, const uint8_t *states, void **d_states_cache, int64_t ncand,
-                       const int32_t *cand_locus, const double *cand_exch, const double *cand_blen, double *out);
+int tphip_locus_loglik(tphip_plan *plan, const uint8_t *states, void **d_states_cache, int64_t nvec,
+                       const double *blen_vecs, int64_t ncand, const int32_t *cand_locus, const double *cand_exch,
+                       const int32_t *cand_vec, const double *cand_scale, const int32_t *cand_pidx,
+                       const double *cand_pfac, double *out);
 int tphip_free_device(tphip_plan *plan, void *d_ptr);
 
 /* Diagnostic (tests): log L and its first two derivatives with respect to u = log(siteRate) for every

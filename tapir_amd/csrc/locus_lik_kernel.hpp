@@ -37,7 +37,14 @@ struct LikParams {
     int32_t stack_depth;
     const int32_t* cand_locus;     // [ncand]
     const double* cand_exch;       // [ncand][6] AC,AG,AT,CG,CT,GT
-    const double* cand_blen;       // [ncand][nnodes] branch length above each node
+    // branch lengths of candidate c: blen_vecs[cand_vec[c]][b] * cand_scale[c] * (b == cand_pidx[c] ? cand_pfac[c] : 1).
+    // A finite-difference stencil around one point, or the 202 rate-class models of one locus (which only rescale
+    // the stashed lengths, bf:613-619), therefore share ONE stored vector instead of carrying nnodes doubles each.
+    const double* blen_vecs;       // [nvec][nnodes]
+    const int32_t* cand_vec;       // [ncand]
+    const double* cand_scale;      // [ncand]
+    const int32_t* cand_pidx;      // [ncand] node whose branch is perturbed, -1 for none
+    const double* cand_pfac;       // [ncand]
     double* out;                   // [ncand] sum over columns of log L
 };
 
@@ -84,10 +91,12 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
     }
     __syncthreads();
     // transition matrices: P_b[i][j] = sum_k U[i][k] exp(lam_k t_b) Ui[k][j]
-    const double* bl = P.cand_blen + (size_t)cand * P.nnodes;
+    const double* bl = P.blen_vecs + (size_t)P.cand_vec[cand] * P.nnodes;
+    const double bscale = P.cand_scale[cand], pfac = P.cand_pfac[cand];
+    const int pidx = P.cand_pidx[cand];
     for (int idx = threadIdx.x; idx < P.nnodes * 16; idx += kLikBlock) {
         const int b = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
-        const double t = bl[b];
+        const double t = bl[b] * bscale * (b == pidx ? pfac : 1.0);
         double s = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) s = fma(eig[4 + i * 4 + k] * exp(eig[k] * t), eig[20 + k * 4 + j], s);

@@ -485,17 +485,21 @@ int tphip_quad_townsend_dev(int32_t device, const double* d_rates, int64_t n, do
 }
 
 int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand, const int32_t* d_cand_locus,
-                           const double* d_cand_exch, const double* d_cand_blen, double* d_out, void* stream) {
+                           const double* d_cand_exch, const double* d_blen_vecs, const int32_t* d_cand_vec,
+                           const double* d_cand_scale, const int32_t* d_cand_pidx, const double* d_cand_pfac, double* d_out,
+                           void* stream) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
-    if (ncand < 0 || (ncand && (!d_states || !d_cand_locus || !d_cand_exch || !d_cand_blen || !d_out)))
+    if (ncand < 0 || (ncand && (!d_states || !d_cand_locus || !d_cand_exch || !d_blen_vecs || !d_cand_vec || !d_cand_scale ||
+                                !d_cand_pidx || !d_cand_pfac || !d_out)))
         return fail(TPHIP_ERR_INVALID, "null device pointer");
     if (ncand == 0) return TPHIP_OK;
     HIP_TRY(hipSetDevice(p->device));
     LikParams L;
     L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;
     L.ops = p->d_ops.p; L.op_node = p->d_op_node.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes;
-    L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch; L.cand_blen = d_cand_blen;
-    L.out = d_out;
+    L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
+    L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
+    L.cand_pfac = d_cand_pfac; L.out = d_out;
     const size_t lds = ((size_t)p->nnodes * 16 + (size_t)p->prog.stack_depth * 4 * kLikBlock) * sizeof(double);
     if (lds > 150 * 1024) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-likelihood kernel's LDS tables");
     static bool attr_set = false;
@@ -503,7 +507,13 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
         HIP_TRY(hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    locus_loglik_kernel<<<dim3((unsigned)ncand), dim3(kLikBlock), lds, (hipStream_t)stream>>>(L);
+    for (int64_t done = 0; done < ncand; done += (int64_t)1 << 30) {  // grid.x limit
+        const int64_t n = std::min<int64_t>(ncand - done, (int64_t)1 << 30);
+        LikParams Q = L;
+        Q.cand_locus += done; Q.cand_exch += done * 6; Q.cand_vec += done; Q.cand_scale += done; Q.cand_pidx += done;
+        Q.cand_pfac += done; Q.out += done;
+        locus_loglik_kernel<<<dim3((unsigned)n), dim3(kLikBlock), lds, (hipStream_t)stream>>>(Q);
+    }
     HIP_TRY(hipGetLastError());
     return TPHIP_OK;
 }
@@ -667,13 +677,18 @@ int tphip_free_device(tphip_plan* p, void* d_ptr) {
     return TPHIP_OK;
 }
 
-int tphip_locus_loglik(tphip_plan* p, const uint8_t* states, void** d_states_cache, int64_t ncand, const int32_t* cand_locus,
-                       const double* cand_exch, const double* cand_blen, double* out) {
-    if (!p || !states || ncand < 0 || (ncand && (!cand_locus || !cand_exch || !cand_blen || !out)))
+int tphip_locus_loglik(tphip_plan* p, const uint8_t* states, void** d_states_cache, int64_t nvec, const double* blen_vecs,
+                       int64_t ncand, const int32_t* cand_locus, const double* cand_exch, const int32_t* cand_vec,
+                       const double* cand_scale, const int32_t* cand_pidx, const double* cand_pfac, double* out) {
+    if (!p || !states || ncand < 0 || nvec < 0 ||
+        (ncand && (!blen_vecs || !cand_locus || !cand_exch || !cand_vec || !cand_scale || !cand_pidx || !cand_pfac || !out)))
         return fail(TPHIP_ERR_INVALID, "null argument");
     if (ncand == 0) return TPHIP_OK;
-    for (int64_t c = 0; c < ncand; ++c)
+    for (int64_t c = 0; c < ncand; ++c) {
         if (cand_locus[c] < 0 || cand_locus[c] >= p->nloci) return fail(TPHIP_ERR_INVALID, "cand_locus out of range");
+        if (cand_vec[c] < 0 || cand_vec[c] >= nvec) return fail(TPHIP_ERR_INVALID, "cand_vec out of range");
+        if (cand_pidx[c] >= p->nnodes) return fail(TPHIP_ERR_INVALID, "cand_pidx out of range");
+    }
     HIP_TRY(hipSetDevice(p->device));
     Scratch S;
     const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
@@ -688,18 +703,27 @@ int tphip_locus_loglik(tphip_plan* p, const uint8_t* states, void** d_states_cac
         }
         HIP_TRY(hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice));
     }
-    int32_t* d_l = S.get<int32_t>((size_t)ncand);
-    double* d_e = S.get<double>((size_t)ncand * 6);
-    double* d_b = S.get<double>((size_t)ncand * (size_t)p->nnodes);
-    double* d_o = S.get<double>((size_t)ncand);
-    if (!d_l || !d_e || !d_b || !d_o) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
-    HIP_TRY(hipMemcpy(d_l, cand_locus, sizeof(int32_t) * (size_t)ncand, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_e, cand_exch, sizeof(double) * (size_t)ncand * 6, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_b, cand_blen, sizeof(double) * (size_t)ncand * (size_t)p->nnodes, hipMemcpyHostToDevice));
-    int rc = tphip_locus_loglik_dev(p, d_s, ncand, d_l, d_e, d_b, d_o, nullptr);
+    const size_t n = (size_t)ncand;
+    int32_t* d_l = S.get<int32_t>(n);
+    double* d_e = S.get<double>(n * 6);
+    double* d_b = S.get<double>((size_t)nvec * (size_t)p->nnodes);
+    int32_t* d_v = S.get<int32_t>(n);
+    double* d_sc = S.get<double>(n);
+    int32_t* d_pi = S.get<int32_t>(n);
+    double* d_pf = S.get<double>(n);
+    double* d_o = S.get<double>(n);
+    if (!d_l || !d_e || !d_b || !d_v || !d_sc || !d_pi || !d_pf || !d_o) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_l, cand_locus, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_e, cand_exch, sizeof(double) * n * 6, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b, blen_vecs, sizeof(double) * (size_t)nvec * (size_t)p->nnodes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_v, cand_vec, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_sc, cand_scale, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pi, cand_pidx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pf, cand_pfac, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = tphip_locus_loglik_dev(p, d_s, ncand, d_l, d_e, d_b, d_v, d_sc, d_pi, d_pf, d_o, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * (size_t)ncand, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
     return TPHIP_OK;
 }
 

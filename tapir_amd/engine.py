@@ -50,7 +50,7 @@ SYMBOLS = [
     ("tphip_run_dev", ctypes.c_int, [_vp] * 9 + [ctypes.c_size_t, _vp]),
     ("tphip_townsend_pi_dense_dev", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     ("tphip_quad_townsend_dev", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp, _vp]),
-    ("tphip_locus_loglik_dev", ctypes.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    ("tphip_locus_loglik_dev", ctypes.c_int, [_vp, _vp, _i64] + [_vp] * 9),
     ("tphip_state_histogram_dev", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     ("tphip_profile_enable", ctypes.c_int, [_vp, _i32]),
     ("tphip_profile_read", ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_f64), ctypes.POINTER(_i64), _i32]),
@@ -62,7 +62,7 @@ SYMBOLS = [
     ("tphip_quad_townsend", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp]),
     ("tphip_state_histogram", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     ("tphip_eval_columns", ctypes.c_int, [_vp] * 6),
-    ("tphip_locus_loglik", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _vp, _vp, _vp]),
+    ("tphip_locus_loglik", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 7),
     ("tphip_free_device", ctypes.c_int, [_vp, _vp]),
 ]
 
@@ -203,17 +203,27 @@ class Plan:
                                             h.ctypes.data))
         return f, g, h
 
-    def locus_loglik(self, states, cand_locus, cand_exch, cand_blen, cache=None):
-        """Sum over columns of log L for candidate (locus, exchangeabilities[6], branch lengths[nnodes]) sets.
-        cache: a one-element list holding the device copy of `states` between calls (see StatesOnDevice)."""
+    def locus_loglik(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
+                     cand_pfac=None, cache=None):
+        """Sum over columns of log L (site rate 1) for candidate parameter sets (tphip_locus_loglik).
+        Branch lengths of candidate c = blen_vecs[cand_vec[c]] * cand_scale[c], with branch cand_pidx[c]
+        additionally multiplied by cand_pfac[c].  Defaults: vec = arange, scale = 1, no perturbation.
+        cache: device_cache() object that keeps the alignment on the device between calls."""
         states = _np(states, np.uint8)
+        bv = _np(blen_vecs, np.float64)
+        bv = bv.reshape(-1, bv.shape[-1])
         cl = _np(cand_locus, np.int32).reshape(-1)
-        ce = _np(cand_exch, np.float64).reshape(len(cl), 6)
-        cb = _np(cand_blen, np.float64).reshape(len(cl), -1)
-        out = np.empty(len(cl))
+        n = len(cl)
+        ce = _np(cand_exch, np.float64).reshape(n, 6)
+        cv = _np(np.arange(n) if cand_vec is None else cand_vec, np.int32).reshape(n)
+        cs = _np(np.ones(n) if cand_scale is None else cand_scale, np.float64).reshape(n)
+        ci = _np(np.full(n, -1) if cand_pidx is None else cand_pidx, np.int32).reshape(n)
+        cf = _np(np.ones(n) if cand_pfac is None else cand_pfac, np.float64).reshape(n)
+        out = np.empty(n)
         ref = ctypes.byref(cache.ptr) if cache is not None else None
-        _check(self._lib.tphip_locus_loglik(self._h, states.ctypes.data, ref, len(cl), cl.ctypes.data, ce.ctypes.data,
-                                            cb.ctypes.data, out.ctypes.data))
+        _check(self._lib.tphip_locus_loglik(self._h, states.ctypes.data, ref, bv.shape[0], bv.ctypes.data, n, cl.ctypes.data,
+                                            ce.ctypes.data, cv.ctypes.data, cs.ctypes.data, ci.ctypes.data, cf.ctypes.data,
+                                            out.ctypes.data))
         return out
 
     def device_cache(self):

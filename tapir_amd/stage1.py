@@ -1,0 +1,317 @@
+"""HyPhy stage 1 on the GPU: model-averaged GTR exchangeabilities per locus.
+
+What it replaces (tapir/data/models_and_rates.bf, "next" row #1 of SURVEY.md section 8f):
+
+  bf:487-520   general reversible model (012345): `Optimize(lf_MLES, lf)` over the 5 exchangeabilities
+               AC, AT, CG, CT, GT (AG = 1) AND every branch length;
+  bf:522-540   stash the fitted branch lengths in expected substitutions (t_b * totalFactor,
+               totalFactor = 2 sum_{i<j} pi_i pi_j r_ij);
+  bf:542-661   the other 202 set partitions of the six rates (restricted growth strings, in the script's loop
+               order): rates of one class are equal, the class holding AG is 1, branch lengths are the stashed
+               ones divided by the model's own totalFactor (bf:613-619); optimise the <= 4 free class rates;
+  bf:806-831   Akaike weights from c_m = 2 (np_m - lnL_m + log sites): w_m proportional to exp(lnL_m - k_m),
+               k_m = number of free rates (everything else in np_m is the same for all models);
+  bf:838-847   modelAveragedRates[v] = sum_m w_m rate_m[v]  ->  the AC, AT, CG, CT, GT handed to stage 2.
+
+Division of labour: every likelihood is evaluated on the GPU by `locus_loglik_kernel` (one workgroup per
+(locus, candidate point)); this module is the optimiser around it, written once for ALL loci (and all 202
+models) at a time in numpy: batched L-BFGS on log-parameters with central-difference gradients.  A finite
+difference stencil costs no extra branch-length storage (the kernel perturbs one branch of a shared vector).
+
+Parity: HyPhy's own optimiser and its results for this stage are pinned by no fixture of the reference
+("parity unpinned"); the stage is checked against an independent CPU restatement
+(tests/test_gpu_stage1.py: oracle likelihood + scipy L-BFGS-B) at 1e-3 relative on the averaged rates.
+"""
+import numpy as np
+
+RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
+_PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
+
+
+def model_strings():
+    """The 203 rate-class models as restricted growth strings over (AC, AG, AT, CG, CT, GT): '012345' (the general
+    reversible model, fitted first, bf:487) followed by the other 202 in the order of the loops at bf:544-566."""
+    out = ["012345"]
+    for v2 in range(0, 2):
+        for v3 in range(0, v2 + 2):
+            ub4 = v3 if v3 > v2 else v2
+            for v4 in range(0, ub4 + 2):
+                ub5 = v4 if v4 >= ub4 else ub4
+                for v5 in range(0, ub5 + 2):
+                    ub6 = v5 if v5 > ub5 else ub5
+                    for v6 in range(0, ub6 + 2):
+                        if v6 == 5:
+                            break
+                        out.append("0%d%d%d%d%d" % (v2, v3, v4, v5, v6))
+    assert len(out) == 203 and len(set(out)) == 203
+    return out
+
+
+def model_design(strings=None):
+    """For each model: class index of every rate with the AG class mapped to -1 (fixed at 1) and the free classes
+    renumbered 0..k-1.  Returns (cls int[203, 6], k int[203])."""
+    strings = strings or model_strings()
+    cls = np.zeros((len(strings), 6), dtype=np.int64)
+    k = np.zeros(len(strings), dtype=np.int64)
+    for m, s in enumerate(strings):
+        ag = s[1]
+        free = []
+        for c in s:
+            if c != ag and c not in free:
+                free.append(c)
+        k[m] = len(free)
+        cls[m] = [-1 if c == ag else free.index(c) for c in s]
+    return cls, k
+
+
+def total_factor(pi, exch):
+    """totalFactor of bf:531-534 = expected substitutions per unit t: 2 sum_{i<j} pi_i pi_j r_ij."""
+    pi = np.asarray(pi, dtype=np.float64)
+    exch = np.asarray(exch, dtype=np.float64)
+    w = np.stack([2.0 * pi[..., i] * pi[..., j] for i, j in _PAIRS], axis=-1)
+    return (w * exch).sum(axis=-1)
+
+
+class _LBFGS:
+    """Batched L-BFGS (maximisation written as minimisation of -lnL) over P independent problems of dimension D.
+    `value(X, idx)` evaluates points X[len(idx), D] of problems idx; `value_and_grad(X, idx)` adds gradients."""
+
+    def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=1e-5):
+        self.value, self.vg = value, value_and_grad
+        self.x = np.array(x0, dtype=np.float64)
+        P, D = self.x.shape
+        self.active = np.ones((P, D), bool) if active is None else active
+        self.m, self.maxit, self.ftol, self.gtol = history, maxit, ftol, gtol
+
+    def run(self):
+        P, D = self.x.shape
+        live = np.arange(P)
+        f, g = self.vg(self.x, live)
+        g = np.where(self.active, g, 0.0)
+        S = np.zeros((self.m, P, D)); Y = np.zeros((self.m, P, D)); rho = np.zeros((self.m, P))
+        nhist = np.zeros(P, dtype=np.int64)
+        converged = np.zeros(P, bool)
+        self.iters = np.zeros(P, dtype=np.int64)
+        for it in range(self.maxit):
+            live = np.flatnonzero(~converged)
+            if live.size == 0:
+                break
+            # two-loop recursion on the live problems
+            q = g[live].copy()
+            alpha = np.zeros((self.m, live.size))
+            for i in range(self.m - 1, -1, -1):
+                use = (nhist[live] > (self.m - 1 - i)) if False else (i >= self.m - nhist[live])
+                a = np.where(use, rho[i, live] * (S[i, live] * q).sum(1), 0.0)
+                alpha[i] = a
+                q -= a[:, None] * Y[i, live]
+            last = self.m - 1
+            sy = (S[last, live] * Y[last, live]).sum(1)
+            yy = (Y[last, live] * Y[last, live]).sum(1)
+            gamma = np.where((nhist[live] > 0) & (yy > 0), sy / np.maximum(yy, 1e-300), 1.0)
+            r = gamma[:, None] * q
+            for i in range(self.m):
+                use = i >= self.m - nhist[live]
+                b = np.where(use, rho[i, live] * (Y[i, live] * r).sum(1), 0.0)
+                r += (alpha[i] - b)[:, None] * S[i, live]
+            d = -r
+            gd = (g[live] * d).sum(1)
+            bad = ~(gd < 0)
+            d[bad] = -g[live][bad]
+            gd[bad] = -(g[live][bad] ** 2).sum(1)
+            # first iteration: a cautious step length
+            step0 = np.where(nhist[live] == 0, np.minimum(1.0, 1.0 / np.maximum(np.abs(g[live]).max(1), 1e-300)), 1.0)
+            # cap the step in log-parameter space
+            dmax = np.abs(d).max(1)
+            step0 = np.minimum(step0, 2.0 / np.maximum(dmax, 1e-300))
+            t = step0.copy()
+            xnew = self.x[live].copy(); fnew = f[live].copy()
+            pending = np.arange(live.size)
+            for _ in range(30):
+                if pending.size == 0:
+                    break
+                xt = self.x[live][pending] + t[pending, None] * d[pending]
+                ft = self.value(xt, live[pending])
+                ok = ft <= f[live][pending] + 1e-4 * t[pending] * gd[pending]
+                ok &= np.isfinite(ft)
+                acc = pending[ok]
+                xnew[acc] = xt[ok]; fnew[acc] = ft[ok]
+                pending = pending[~ok]
+                t[pending] *= 0.5
+            failed = np.zeros(live.size, bool)
+            failed[pending] = True  # no decrease found: treat as converged at the current point
+            fx, gx = self.vg(xnew, live)
+            gx = np.where(self.active[live], gx, 0.0)
+            s_ = xnew - self.x[live]
+            y_ = gx - g[live]
+            sy = (s_ * y_).sum(1)
+            upd = (sy > 1e-12 * np.sqrt((s_ * s_).sum(1) * (y_ * y_).sum(1) + 1e-300)) & ~failed
+            li = live[upd]
+            S[:, li] = np.roll(S[:, li], -1, axis=0); Y[:, li] = np.roll(Y[:, li], -1, axis=0)
+            rho[:, li] = np.roll(rho[:, li], -1, axis=0)
+            S[-1, li] = s_[upd]; Y[-1, li] = y_[upd]; rho[-1, li] = 1.0 / sy[upd]
+            nhist[li] = np.minimum(nhist[li] + 1, self.m)
+            df = f[live] - fx
+            done = failed | ((df <= self.ftol * (1.0 + np.abs(fx))) & (np.abs(gx).max(1) <= self.gtol * (1.0 + np.abs(fx))))
+            done |= np.abs(gx).max(1) <= 1e-9
+            self.x[live] = xnew; f[live] = fx; g[live] = gx
+            self.iters[live] += 1
+            converged[live[done]] = True
+        self.f, self.g = f, g
+        return self.x, f
+
+
+class Stage1:
+    """Model-averaged exchangeabilities for every locus of a plan (see module docstring)."""
+
+    def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, verbose=False):
+        self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
+        self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
+        self.pi = self.pi / self.pi.sum(1, keepdims=True)
+        parent = np.asarray(parent)
+        self.branches = np.flatnonzero(parent >= 0)          # nodes that carry a branch
+        self.nn = len(parent)
+        self.blen0 = np.asarray(blen, dtype=np.float64)
+        self.h = fd_step
+        self.cache = plan.device_cache()
+        self.verbose = verbose
+        self.nevals = 0
+
+    def close(self):
+        self.cache.release()
+
+    # ---- likelihood calls ---------------------------------------------------------------------------------
+    def _lik(self, vecs, locus, exch, vec=None, scale=None, pidx=None, pfac=None):
+        self.nevals += len(locus)
+        return self.plan.locus_loglik(self.states, vecs, locus, exch, vec, scale, pidx, pfac, cache=self.cache)
+
+    @staticmethod
+    def _exch_from_free(logr5):
+        """[.., 5] log(AC, AT, CG, CT, GT) -> [.., 6] AC, AG=1, AT, CG, CT, GT."""
+        r = np.exp(logr5)
+        return np.stack([r[..., 0], np.ones_like(r[..., 0]), r[..., 1], r[..., 2], r[..., 3], r[..., 4]], axis=-1)
+
+    # ---- general reversible model: 5 rates + all branch lengths -------------------------------------------
+    def _grm_value(self, X, idx):
+        vecs = np.zeros((len(idx), self.nn))
+        vecs[:, self.branches] = np.exp(X[:, 5:])
+        return -self._lik(vecs, idx, self._exch_from_free(X[:, :5]))
+
+    def _grm_value_and_grad(self, X, idx):
+        n, D = X.shape
+        nb = len(self.branches)
+        h = self.h
+        vecs = np.zeros((n, self.nn))
+        vecs[:, self.branches] = np.exp(X[:, 5:])
+        # candidates per problem: base, +-h on each log-rate (exchangeabilities change), +-h on each log-branch
+        # (the kernel multiplies one branch of the shared vector by exp(+-h))
+        per = 1 + 2 * D
+        loc = np.repeat(idx, per)
+        vec = np.repeat(np.arange(n), per)
+        logr = np.repeat(X[:, None, :5], per, axis=1)
+        pidx = np.full((n, per), -1, dtype=np.int64)
+        pfac = np.ones((n, per))
+        for j in range(5):
+            logr[:, 1 + 2 * j, j] += h
+            logr[:, 2 + 2 * j, j] -= h
+        for b in range(nb):
+            pidx[:, 1 + 2 * (5 + b)] = self.branches[b]; pfac[:, 1 + 2 * (5 + b)] = np.exp(h)
+            pidx[:, 2 + 2 * (5 + b)] = self.branches[b]; pfac[:, 2 + 2 * (5 + b)] = np.exp(-h)
+        f = -self._lik(vecs, loc, self._exch_from_free(logr.reshape(-1, 5)), vec, None, pidx.reshape(-1), pfac.reshape(-1))
+        f = f.reshape(n, per)
+        g = (f[:, 1::2] - f[:, 2::2]) / (2 * h)
+        return f[:, 0], g
+
+    def fit_grm(self, maxit=300):
+        L = self.plan.nloci
+        x0 = np.zeros((L, 5 + len(self.branches)))
+        x0[:, 5:] = np.log(np.maximum(self.blen0[self.branches], 1e-6))[None, :]
+        opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit)
+        x, f = opt.run()
+        self.grm_iters = opt.iters
+        exch = self._exch_from_free(x[:, :5])
+        t = np.zeros((L, self.nn))
+        t[:, self.branches] = np.exp(x[:, 5:])
+        return exch, t, -f
+
+    # ---- the 202 constrained models ---------------------------------------------------------------------
+    def _sub_exch(self, X, cls):
+        """free log class rates X [n, 4] + class map cls [n, 6] -> exchangeabilities [n, 6]."""
+        r = np.exp(X)
+        pick = np.take_along_axis(r, np.maximum(cls, 0), axis=1)
+        return np.where(cls < 0, 1.0, pick)
+
+    def _sub_eval(self, X, prob, cls, stash_locus):
+        exch = self._sub_exch(X, cls)
+        loc = self._sub_locus[prob]
+        scale = 1.0 / total_factor(self.pi[loc], exch)
+        return exch, loc, scale
+
+    def _sub_value(self, X, idx):
+        exch, loc, scale = self._sub_eval(X, idx, self._sub_cls[idx], None)
+        return -self._lik(self._stash, loc, exch, loc, scale)
+
+    def _sub_value_and_grad(self, X, idx):
+        n, D = X.shape
+        h = self.h
+        per = 1 + 2 * D
+        Xr = np.repeat(X[:, None, :], per, axis=1)
+        for j in range(D):
+            Xr[:, 1 + 2 * j, j] += h
+            Xr[:, 2 + 2 * j, j] -= h
+        pr = np.repeat(idx, per)
+        exch, loc, scale = self._sub_eval(Xr.reshape(-1, D), pr, self._sub_cls[pr], None)
+        # skip the stencil points of inactive dimensions (their gradient is defined as zero)
+        act = np.repeat(self._sub_active[idx][:, None, :], 2, axis=2).reshape(n, 2 * D)
+        need = np.concatenate([np.ones((n, 1), bool), act], axis=1).reshape(-1)
+        f = np.zeros(n * per)
+        f[need] = -self._lik(self._stash, loc[need], exch[need], loc[need], scale[need])
+        f = f.reshape(n, per)
+        g = (f[:, 1::2] - f[:, 2::2]) / (2 * h)
+        return f[:, 0], np.where(self._sub_active[idx], g, 0.0)
+
+    def fit_submodels(self, grm_exch, grm_t, maxit=100):
+        L = self.plan.nloci
+        strings = model_strings()
+        cls, k = model_design(strings)
+        M = len(strings) - 1
+        # stashed branch lengths in expected substitutions (bf:522-540)
+        self._stash = grm_t * total_factor(self.pi, grm_exch)[:, None]
+        self._sub_locus = np.repeat(np.arange(L), M)
+        self._sub_cls = np.tile(cls[1:], (L, 1))
+        kk = np.tile(k[1:], L)
+        self._sub_active = np.arange(4)[None, :] < kk[:, None]
+        # start: geometric mean of the general model's rates over each class
+        lg = np.log(grm_exch)[self._sub_locus]                        # [P, 6]
+        x0 = np.zeros((L * M, 4))
+        for c in range(4):
+            inc = self._sub_cls == c
+            cnt = inc.sum(1)
+            x0[:, c] = np.where(cnt > 0, (lg * inc).sum(1) / np.maximum(cnt, 1), 0.0)
+        opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0, active=self._sub_active, maxit=maxit)
+        x, f = opt.run()
+        self.sub_iters = opt.iters
+        exch = self._sub_exch(x, self._sub_cls).reshape(L, M, 6)
+        return exch, (-f).reshape(L, M), k
+
+    # ---- model averaging (bf:806-847) --------------------------------------------------------------------
+    def run(self):
+        grm_exch, grm_t, grm_lnl = self.fit_grm()
+        sub_exch, sub_lnl, k = self.fit_submodels(grm_exch, grm_t)
+        lnl = np.concatenate([grm_lnl[:, None], sub_lnl], axis=1)          # [L, 203]
+        exch = np.concatenate([grm_exch[:, None, :], sub_exch], axis=1)    # [L, 203, 6]
+        score = lnl - k[None, :]                                           # = -AIC/2 + const
+        w = np.exp(score - score.max(axis=1, keepdims=True))
+        w /= w.sum(axis=1, keepdims=True)
+        avg = (w[:, :, None] * exch).sum(axis=1)
+        avg[:, 1] = 1.0
+        return dict(exch=avg, weights=w, lnl=lnl, model_exch=exch, grm_exch=grm_exch, grm_blen=grm_t,
+                    models=model_strings(), nevals=self.nevals)
+
+
+def model_averaged_exchangeabilities(plan, states, pi, parent, blen, **kw):
+    """Convenience wrapper: returns dict with `exch` [L, 6] (AC, AG=1, AT, CG, CT, GT) and diagnostics."""
+    s1 = Stage1(plan, states, pi, parent, blen, **kw)
+    try:
+        return s1.run()
+    finally:
+        s1.close()

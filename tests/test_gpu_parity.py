@@ -419,9 +419,15 @@ def test_locus_loglik_vs_oracle(oracle):
         ce = np.exp(rng.normal(0, 0.5, (ncand, 6)))
         cb = pin["blen"][None, :] * np.exp(rng.normal(0, 0.7, (ncand, nn)))
         cache = plan.device_cache()
-        got = plan.locus_loglik(st, cl, ce, cb, cache=cache)
-        got2 = plan.locus_loglik(st, cl, ce, cb, cache=cache)  # second call reuses the device copy
+        got = plan.locus_loglik(st, cb, cl, ce, cache=cache)
+        got2 = plan.locus_loglik(st, cb, cl, ce, cache=cache)  # second call reuses the device copy
         assert np.array_equal(got, got2)
+        # shared-vector form: vector 3 scaled and with one branch perturbed == the explicit vector
+        exp_vec = cb[3] * 0.7
+        exp_vec[5] *= 1.25
+        a = plan.locus_loglik(st, exp_vec[None, :], [cl[3]], [ce[3]], cache=cache)
+        b = plan.locus_loglik(st, cb, [cl[3]], [ce[3]], cand_vec=[3], cand_scale=[0.7], cand_pidx=[5], cand_pfac=[1.25], cache=cache)
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(a[0])
         cache.release()
         for c in range(ncand):
             l = int(cl[c])
