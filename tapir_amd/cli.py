@@ -8,8 +8,8 @@ Same positionals, same required/optional flags and defaults, same output directo
 --integral-mode, --full-precision-rates.
 
 Stage 1 of the HyPhy script (203-model fit + model averaging of the GTR exchangeabilities,
-models_and_rates.bf:405-897) is not part of this engine yet: the exchangeabilities are an
-input, defaulting to all ones with empirical base frequencies.
+models_and_rates.bf:405-897) runs on the GPU too (tapir_amd/stage1.py) unless the exchangeabilities are given
+with --exchangeabilities / --subs-model.
 """
 import argparse
 import os
@@ -53,7 +53,8 @@ def get_args(argv=None):
     new = parser.add_argument_group("MI355X engine options (not in the reference)")
     new.add_argument('--device', type=int, default=0, help="HIP device ordinal")
     new.add_argument('--exchangeabilities', type=_six_floats, default=None,
-                     help="AC,AG,AT,CG,CT,GT used for every locus (default 1,1,1,1,1,1)")
+                     help="AC,AG,AT,CG,CT,GT used for every locus (default: model-averaged estimates per locus, "
+                          "as the HyPhy script computes them)")
     new.add_argument('--subs-model', default=None,
                      help="tab-delimited file: alignment file name, AC, AG, AT, CG, CT, GT [, A, C, G, T frequencies]")
     new.add_argument('--integral-mode', choices=['quadpack', 'closed'], default='quadpack',
@@ -137,14 +138,11 @@ def main(argv=None, engine_mod=None):
     if not args.site_rates:
         print("\nEstimating site rates and PI for files:")
         alignments = base.get_files(args.alignments, '*.nex,*.nexus')
-        exch, pi = np.ones(6), None
+        exch, pi = None, None  # None: fit and model-average the exchangeabilities per locus (HyPhy stage 1)
         if args.exchangeabilities is not None:
             exch = np.array(args.exchangeabilities)
         if args.subs_model:
             exch, pi = read_subs_model(args.subs_model, alignments)
-        elif args.exchangeabilities is None:
-            sys.stderr.write("tapir_amd: no --exchangeabilities/--subs-model given: using AC=AG=AT=CG=CT=GT=1 with "
-                             "empirical base frequencies (HyPhy's stage-1 model averaging is not part of this engine)\n")
         pis, _ = pipeline.run_alignments(alignments, leaf_names, parent, blen, leaf, T, args.times, args.intervals,
                                          correction, args.threshold, exch, pi=pi, subsets=subset_pi,
                                          output_dir=args.output, device=args.device, integ_mode=integ_mode,

@@ -95,13 +95,27 @@ def _write_one(l):
     return l
 
 
+def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, blen, leaf, T, times, intervals,
+                                     correction, device=0):
+    """Stage 1 of models_and_rates.bf (bf:405-897) for every locus at once -> [L, 6] AC, AG(=1), AT, CG, CT, GT."""
+    from . import stage1
+    L = len(offsets) - 1
+    plan = eng.Plan(ntaxa, parent, blen, leaf, offsets, pi, np.ones((L, 6)), T, times, intervals,
+                    correction=correction, device=device)
+    try:
+        return stage1.model_averaged_exchangeabilities(plan, states, pi, parent, np.asarray(blen) / correction)["exch"]
+    finally:
+        plan.close()
+
+
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
                    exch, pi=None, subsets=None, output_dir=None, device=0, integ_mode=0, round_decimals=4,
                    engine_mod=None, progress=None, workers=1):
     """Site rates + PI for a list of NEXUS alignments.  Returns a list of worker()-shaped tuples
     (alignment, rates, mean_rate, None, pi_net, pi_times, pi_epochs) in the order of `alignments`.
 
-    exch: [6] or [L,6] exchangeabilities AC,AG,AT,CG,CT,GT; pi: None (empirical, HarvestFrequencies) or [L,4]."""
+    exch: [6] or [L,6] exchangeabilities AC,AG,AT,CG,CT,GT, or None = HyPhy's stage 1 (model-averaged estimates per
+    locus, tapir_amd/stage1.py); pi: None (empirical, HarvestFrequencies) or [L,4]."""
     eng = engine_mod
     if eng is None:
         from . import engine as eng
@@ -112,6 +126,9 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
         hist = eng.state_histogram(states, offsets, device=device)
         pi = nexus.base_frequencies_from_histogram(hist)
     pi = np.asarray(pi, dtype=np.float64).reshape(L, 4)
+    if exch is None:
+        exch = model_averaged_exchangeabilities(eng, states, offsets, pi, len(leaf_names), parent, blen, leaf, T, times,
+                                                intervals, correction, device)
     exch = np.asarray(exch, dtype=np.float64)
     if exch.ndim == 1:
         exch = np.tile(exch, (L, 1))

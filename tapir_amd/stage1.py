@@ -25,6 +25,8 @@ Parity: HyPhy's own optimiser and its results for this stage are pinned by no fi
 import numpy as np
 
 RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
+LOG_RATE_MIN, LOG_RATE_MAX = -12.0, 12.0    # exchangeabilities within [6e-6, 1.6e5] (HyPhy: [0, 10000])
+LOG_BLEN_MIN, LOG_BLEN_MAX = -30.0, 4.0     # branch lengths within [1e-13, 55]
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
 
 
@@ -76,10 +78,12 @@ class _LBFGS:
     """Batched L-BFGS (maximisation written as minimisation of -lnL) over P independent problems of dimension D.
     `value(X, idx)` evaluates points X[len(idx), D] of problems idx; `value_and_grad(X, idx)` adds gradients."""
 
-    def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=1e-5):
+    def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=1e-5,
+                 lo=-np.inf, hi=np.inf):
         self.value, self.vg = value, value_and_grad
         self.x = np.array(x0, dtype=np.float64)
         P, D = self.x.shape
+        self.lo, self.hi = np.broadcast_to(lo, (D,)), np.broadcast_to(hi, (D,))
         self.active = np.ones((P, D), bool) if active is None else active
         self.m, self.maxit, self.ftol, self.gtol = history, maxit, ftol, gtol
 
@@ -100,7 +104,7 @@ class _LBFGS:
             q = g[live].copy()
             alpha = np.zeros((self.m, live.size))
             for i in range(self.m - 1, -1, -1):
-                use = (nhist[live] > (self.m - 1 - i)) if False else (i >= self.m - nhist[live])
+                use = i >= self.m - nhist[live]
                 a = np.where(use, rho[i, live] * (S[i, live] * q).sum(1), 0.0)
                 alpha[i] = a
                 q -= a[:, None] * Y[i, live]
@@ -129,7 +133,7 @@ class _LBFGS:
             for _ in range(30):
                 if pending.size == 0:
                     break
-                xt = self.x[live][pending] + t[pending, None] * d[pending]
+                xt = np.clip(self.x[live][pending] + t[pending, None] * d[pending], self.lo, self.hi)
                 ft = self.value(xt, live[pending])
                 ok = ft <= f[live][pending] + 1e-4 * t[pending] * gd[pending]
                 ok &= np.isfinite(ft)
@@ -221,11 +225,28 @@ class Stage1:
         g = (f[:, 1::2] - f[:, 2::2]) / (2 * h)
         return f[:, 0], g
 
+    def initial_branch_lengths(self):
+        """Start of the branch-length search: the input tree's shape (its lengths are in time units, not in
+        substitutions), rescaled per locus to the best of a coarse grid of mean branch lengths 1e-4 .. 1 under the
+        all-ones model.  (HyPhy starts from its own defaults; the optimum does not depend on the start.)"""
+        L = self.plan.nloci
+        shape = np.zeros(self.nn)
+        b = np.maximum(self.blen0[self.branches], 0.0)
+        shape[self.branches] = np.maximum(b / max(b.mean(), 1e-300), 1e-3)
+        grid = 10.0 ** np.linspace(-4.0, 0.0, 17)
+        loc = np.repeat(np.arange(L), len(grid))
+        lnl = self._lik(shape[None, :], loc, np.ones((len(loc), 6)), np.zeros(len(loc), dtype=np.int64),
+                        np.tile(grid, L)).reshape(L, len(grid))
+        best = grid[np.argmax(lnl, axis=1)]
+        return best[:, None] * shape[None, :]
+
     def fit_grm(self, maxit=300):
         L = self.plan.nloci
         x0 = np.zeros((L, 5 + len(self.branches)))
-        x0[:, 5:] = np.log(np.maximum(self.blen0[self.branches], 1e-6))[None, :]
-        opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit)
+        x0[:, 5:] = np.log(self.initial_branch_lengths()[:, self.branches])
+        lo = np.concatenate([np.full(5, LOG_RATE_MIN), np.full(len(self.branches), LOG_BLEN_MIN)])
+        hi = np.concatenate([np.full(5, LOG_RATE_MAX), np.full(len(self.branches), LOG_BLEN_MAX)])
+        opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi)
         x, f = opt.run()
         self.grm_iters = opt.iters
         exch = self._exch_from_free(x[:, :5])
@@ -240,14 +261,14 @@ class Stage1:
         pick = np.take_along_axis(r, np.maximum(cls, 0), axis=1)
         return np.where(cls < 0, 1.0, pick)
 
-    def _sub_eval(self, X, prob, cls, stash_locus):
+    def _sub_eval(self, X, prob, cls):
         exch = self._sub_exch(X, cls)
         loc = self._sub_locus[prob]
         scale = 1.0 / total_factor(self.pi[loc], exch)
         return exch, loc, scale
 
     def _sub_value(self, X, idx):
-        exch, loc, scale = self._sub_eval(X, idx, self._sub_cls[idx], None)
+        exch, loc, scale = self._sub_eval(X, idx, self._sub_cls[idx])
         return -self._lik(self._stash, loc, exch, loc, scale)
 
     def _sub_value_and_grad(self, X, idx):
@@ -259,7 +280,7 @@ class Stage1:
             Xr[:, 1 + 2 * j, j] += h
             Xr[:, 2 + 2 * j, j] -= h
         pr = np.repeat(idx, per)
-        exch, loc, scale = self._sub_eval(Xr.reshape(-1, D), pr, self._sub_cls[pr], None)
+        exch, loc, scale = self._sub_eval(Xr.reshape(-1, D), pr, self._sub_cls[pr])
         # skip the stencil points of inactive dimensions (their gradient is defined as zero)
         act = np.repeat(self._sub_active[idx][:, None, :], 2, axis=2).reshape(n, 2 * D)
         need = np.concatenate([np.ones((n, 1), bool), act], axis=1).reshape(-1)
@@ -287,7 +308,8 @@ class Stage1:
             inc = self._sub_cls == c
             cnt = inc.sum(1)
             x0[:, c] = np.where(cnt > 0, (lg * inc).sum(1) / np.maximum(cnt, 1), 0.0)
-        opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0, active=self._sub_active, maxit=maxit)
+        opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0, active=self._sub_active, maxit=maxit,
+                     lo=LOG_RATE_MIN, hi=LOG_RATE_MAX)
         x, f = opt.run()
         self.sub_iters = opt.iters
         exch = self._sub_exch(x, self._sub_cls).reshape(L, M, 6)

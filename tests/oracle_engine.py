@@ -45,6 +45,31 @@ class Plan:
     def close(self):
         pass
 
+    class _Cache:
+        def release(self):
+            pass
+
+    def device_cache(self):
+        return Plan._Cache()
+
+    def locus_loglik(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
+                     cand_pfac=None, cache=None):
+        states = np.asarray(states, np.uint8)
+        bv = np.asarray(blen_vecs, np.float64)
+        bv = bv.reshape(-1, bv.shape[-1])
+        n = len(cand_locus)
+        ce = np.asarray(cand_exch, np.float64).reshape(n, 6)
+        out = np.empty(n)
+        for c in range(n):
+            b = bv[c if cand_vec is None else cand_vec[c]].copy()
+            if cand_scale is not None:
+                b *= cand_scale[c]
+            if cand_pidx is not None and cand_pidx[c] >= 0:
+                b[cand_pidx[c]] *= cand_pfac[c]
+            l = cand_locus[c]
+            out[c] = orc.locus_loglik(states[:, self.off[l]:self.off[l + 1]], self.parent, b, self.leaf, self.pi[l], ce[c])
+        return out
+
     def site_rates(self, states):
         states = np.asarray(states, np.uint8)
         out = dict(rate=np.empty(self.ncols), subst=np.empty(self.ncols), lnl=np.empty(self.ncols),

@@ -422,3 +422,69 @@ def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, or
     a = sqlite3.connect(outs[0] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
     b = sqlite3.connect(outs[1] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
     assert a == b and len(a) == 6 * 100
+
+
+def test_stage1_model_enumeration():
+    """The 203 rate-class models of models_and_rates.bf:544-566: the script's loop order, every set partition of
+    the six rates exactly once, and the number of free rates per model (class of AG is fixed at 1)."""
+    from oracle import stage1_oracle
+    from tapir_amd import stage1
+    ms = stage1.model_strings()
+    assert ms[0] == "012345" and ms[1] == "000000" and len(ms) == 203
+    assert sorted(ms) == sorted(stage1_oracle.partitions6())
+    cls, k = stage1.model_design(ms)
+    assert k[0] == 5 and k[1] == 0 and k.max() == 5 and (k[1:] <= 4).all()
+    i = ms.index("010010")  # HKY85: transitions (AG, CT) vs transversions
+    assert k[i] == 1 and list(cls[i]) == [0, -1, 0, 0, -1, 0]
+    pi = np.array([0.1, 0.2, 0.3, 0.4])
+    assert abs(stage1.total_factor(pi, np.ones(6)) - (1 - (pi ** 2).sum())) < 1e-15
+
+
+def test_stage1_optimiser_against_independent_restatement(tmp_path):
+    """Host logic of stage 1 (batched L-BFGS, finite-difference stencils, Akaike averaging) with the oracle's
+    likelihood behind the engine interface, against oracle/stage1_oracle.py (scipy L-BFGS-B, one model at a
+    time).  Parity unpinned against HyPhy itself: the reference holds no stage-1 output."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    from oracle import stage1_oracle
+    from tapir_amd import stage1, synth
+    d = synth.simulate(2, 120, 5, 11)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    pi = np.asarray(d["pi"])
+    blen = np.asarray(pin["blen"]) / pin["correction"]
+    plan = oracle_engine.Plan(5, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((2, 6)), pin["T"],
+                              [1], [[0, 1]])
+    got = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen)
+    assert got["exch"].shape == (2, 6) and np.all(got["exch"][:, 1] == 1.0)
+    assert np.allclose(got["weights"].sum(1), 1.0)
+    for l in range(2):
+        ref = stage1_oracle.model_averaged(st[:, l * 120:(l + 1) * 120], pin["parent"], blen, pin["leaf"], pi[l])
+        assert np.max(np.abs(got["exch"][l] - ref["exch"]) / ref["exch"]) < 1e-3
+        lnl = np.array([ref["lnl"][m] for m in got["models"]])
+        assert np.max(np.abs(lnl - got["lnl"][l])) < 1e-3
+        w = np.array([ref["weights"][m] for m in got["models"]])
+        assert np.max(np.abs(w - got["weights"][l])) < 1e-4
+
+
+def test_cli_default_runs_model_averaging(tmp_path):
+    """Without --exchangeabilities/--subs-model the command line does what the reference's HyPhy script does:
+    estimates the exchangeabilities per locus (stage 1) and reports them in every .rates file."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    from tapir_amd import cli, nexus, stage1, synth, newick, compute
+    d = synth.simulate(2, 60, 4, 5)
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    tree = synth.write_nexus_dir(str(aln), d["states"].numpy(), d["locus_offsets"], d["names"], d["root"])
+    shutil.move(tree, tmp_path / "tree.newick")
+    out = tmp_path / "out"
+    out.mkdir()
+    cli.main([str(aln), str(tmp_path / "tree.newick"), "--output", str(out), "--times", "10", "--intervals", "5-15"],
+             engine_mod=oracle_engine)
+    files = sorted(f for f in os.listdir(out) if f.endswith(".rates"))
+    assert len(files) == 2
+    mats = [json.load(open(out / f))["sites"]["subs_matrix"] for f in files]
+    for m in mats:
+        assert m["AG"] == 1.0 and all(m[k] > 0 for k in m)
+    assert mats[0] != mats[1]  # per-locus estimates, not a shared constant
