@@ -171,6 +171,17 @@ int tphip_locus_loglik_dev(tphip_plan *plan, const uint8_t *d_states, int64_t nc
                            const double *d_cand_scale, const int32_t *d_cand_pidx, const double *d_cand_pfac,
                            double *d_out, void *stream);
 
+/* Value AND gradient of the same objective from one forward + one reverse sweep of the pruning recursion
+ * (reverse-mode differentiation; replaces a finite-difference stencil of 2 x (5 + 2N-3) likelihood evaluations).
+ * Candidates are described exactly as for tphip_locus_loglik_dev.  Outputs per candidate:
+ *   d_lnl[c]; d_dexch[c][6] = d lnL / d (AC, AG, AT, CG, CT, GT) with branch lengths held fixed;
+ *   d_dlogt[c][nnodes] = d lnL / d log t_b (root entry 0; may be NULL); d_sum_dlogt[c] = its sum over branches
+ *   (the only branch-length derivative a rate-class model needs: bf:613-619 ties all lengths to one factor). */
+int tphip_locus_gradient_dev(tphip_plan *plan, const uint8_t *d_states, int64_t ncand, const int32_t *d_cand_locus,
+                             const double *d_cand_exch, const double *d_blen_vecs, const int32_t *d_cand_vec,
+                             const double *d_cand_scale, const int32_t *d_cand_pidx, const double *d_cand_pfac,
+                             double *d_lnl, double *d_dexch, double *d_dlogt, double *d_sum_dlogt, void *stream);
+
 /* Profiling hooks for bench.py: when enabled the library brackets its dominant kernel (site rates) with
  * HIP events on the caller's stream and accumulates the elapsed time. */
 int tphip_profile_enable(tphip_plan *plan, int32_t on);
@@ -200,6 +211,11 @@ int tphip_locus_loglik(tphip_plan *plan, const uint8_t *states, void **d_states_
                        const double *blen_vecs, int64_t ncand, const int32_t *cand_locus, const double *cand_exch,
                        const int32_t *cand_vec, const double *cand_scale, const int32_t *cand_pidx,
                        const double *cand_pfac, double *out);
+/* host-pointer twin of tphip_locus_gradient_dev (dlogt may be NULL) */
+int tphip_locus_gradient(tphip_plan *plan, const uint8_t *states, void **d_states_cache, int64_t nvec,
+                         const double *blen_vecs, int64_t ncand, const int32_t *cand_locus, const double *cand_exch,
+                         const int32_t *cand_vec, const double *cand_scale, const int32_t *cand_pidx,
+                         const double *cand_pfac, double *lnl, double *dexch, double *dlogt, double *sum_dlogt);
 int tphip_free_device(tphip_plan *plan, void *d_ptr);
 
 /* Diagnostic (tests): log L and its first two derivatives with respect to u = log(siteRate) for every

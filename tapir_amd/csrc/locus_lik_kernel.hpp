@@ -48,6 +48,40 @@ struct LikParams {
     double* out;                   // [ncand] sum over columns of log L
 };
 
+// Eigen-system of Q = R o pi for one candidate (single thread): eig = lam[4], U[16] (row-major, columns are right
+// eigenvectors), Ui[16] = U^-1.  Symmetrised by sqrt(pi) and diagonalised with cyclic Jacobi sweeps.
+__device__ inline void lik_eigen(const double* pi, const double* e, double* eig) {
+    double R[4][4] = {{0, e[0], e[1], e[2]}, {e[0], 0, e[3], e[4]}, {e[1], e[3], 0, e[5]}, {e[2], e[4], e[5], 0}};
+    double A[4][4], V[4][4], sq[4];
+    for (int i = 0; i < 4; ++i) sq[i] = sqrt(pi[i]);
+    for (int i = 0; i < 4; ++i) {
+        double row = 0;
+        for (int j = 0; j < 4; ++j)
+            if (j != i) { row += R[i][j] * pi[j]; A[i][j] = sq[i] * R[i][j] * sq[j]; }
+        A[i][i] = -row;
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-290) break;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+            const double apq = A[p][q];
+            if (apq == 0.0) continue;
+            const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < 4; ++k) { double x = A[k][p], y = A[k][q]; A[k][p] = c * x - s * y; A[k][q] = s * x + c * y; }
+            for (int k = 0; k < 4; ++k) { double x = A[p][k], y = A[q][k]; A[p][k] = c * x - s * y; A[q][k] = s * x + c * y; }
+            for (int k = 0; k < 4; ++k) { double x = V[k][p], y = V[k][q]; V[k][p] = c * x - s * y; V[k][q] = s * x + c * y; }
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        eig[k] = A[k][k];
+        for (int i = 0; i < 4; ++i) { eig[4 + i * 4 + k] = V[i][k] / sq[i]; eig[20 + k * 4 + i] = V[i][k] * sq[i]; }
+    }
+}
+
 __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
     extern __shared__ double lds[];
     double* Pm = lds;                                   // [nnodes][16]
@@ -57,38 +91,7 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
     const int cand = blockIdx.x;
     const int locus = P.cand_locus[cand];
     const double* pi = P.models[locus].pi;
-    if (threadIdx.x == 0) {
-        const double* e = P.cand_exch + (size_t)cand * 6;
-        double R[4][4] = {{0, e[0], e[1], e[2]}, {e[0], 0, e[3], e[4]}, {e[1], e[3], 0, e[5]}, {e[2], e[4], e[5], 0}};
-        double A[4][4], V[4][4], sq[4];
-        for (int i = 0; i < 4; ++i) sq[i] = sqrt(pi[i]);
-        for (int i = 0; i < 4; ++i) {
-            double row = 0;
-            for (int j = 0; j < 4; ++j)
-                if (j != i) { row += R[i][j] * pi[j]; A[i][j] = sq[i] * R[i][j] * sq[j]; }
-            A[i][i] = -row;
-        }
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-        for (int sweep = 0; sweep < 30; ++sweep) {
-            double off = 0;
-            for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
-            if (off < 1e-290) break;
-            for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
-                const double apq = A[p][q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 4; ++k) { double x = A[k][p], y = A[k][q]; A[k][p] = c * x - s * y; A[k][q] = s * x + c * y; }
-                for (int k = 0; k < 4; ++k) { double x = A[p][k], y = A[q][k]; A[p][k] = c * x - s * y; A[q][k] = s * x + c * y; }
-                for (int k = 0; k < 4; ++k) { double x = V[k][p], y = V[k][q]; V[k][p] = c * x - s * y; V[k][q] = s * x + c * y; }
-            }
-        }
-        for (int k = 0; k < 4; ++k) {
-            eig[k] = A[k][k];
-            for (int i = 0; i < 4; ++i) { eig[4 + i * 4 + k] = V[i][k] / sq[i]; eig[20 + k * 4 + i] = V[i][k] * sq[i]; }
-        }
-    }
+    if (threadIdx.x == 0) lik_eigen(pi, P.cand_exch + (size_t)cand * 6, eig);
     __syncthreads();
     // transition matrices: P_b[i][j] = sum_k U[i][k] exp(lam_k t_b) Ui[k][j]
     const double* bl = P.blen_vecs + (size_t)P.cand_vec[cand] * P.nnodes;
@@ -160,6 +163,312 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = total;
     __syncthreads();
     if (threadIdx.x == 0) P.out[cand] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ---- value + gradient --------------------------------------------------------------------------------------
+//
+// locus_grad_kernel: log-likelihood of a candidate AND its derivatives w.r.t. every branch length and all six
+// exchangeabilities from one forward + one reverse sweep over the op stream (reverse-mode differentiation of the
+// pruning recursion), instead of 2 x (5 + 2N-3) extra likelihood evaluations for a finite-difference stencil.
+//
+//   forward : as locus_loglik_kernel, and the partial entering every BRANCH and every PUSHed partial go to a tape
+//             in global memory, [slot][state][thread] (coalesced; ~1.5 (N-2) slots of 32 B per column);
+//   reverse : carries abar = d log L / d acc back through the ops.  For a branch b with incoming partial a and
+//             outgoing adjoint abar, with x = U^T abar and y = U^-1 a in the eigenbasis of Q:
+//                 d log L / d t_b          = sum_k x_k lam_k e^{lam_k t_b} y_k
+//                 d log L / d theta (in Q) = sum_kl x_k F_kl(t_b) y_l G_kl,   G = U^-1 (dQ/dtheta) U,
+//                 F_kl = (e^{lam_k t} - e^{lam_l t}) / (lam_k - lam_l),  F_kk = t e^{lam_k t}   (Daleckii-Krein)
+//             so the exchangeability derivatives of ALL branches and columns collapse into one 4x4 matrix
+//             W_kl = sum x_k F_kl y_l per candidate, contracted with G for the six rates at the very end.
+//             Tip branches are the same with a = the tip's 0/1 state vector (y from a 16-entry table by state mask)
+//             and abar = the adjoint of the tip's message; the running partial is un-multiplied (acc / message).
+//   outputs : lnL, d lnL / d r (6), d lnL / d log t_b (per branch, optional) and its sum over branches (what a
+//             rate-class model needs, whose branch lengths are one stashed vector times 1/totalFactor(rates)).
+constexpr int kGradBlock = 128;
+constexpr int kGradWaves = kGradBlock / 64;
+constexpr int kGradEF = 12;  // per node: e^{lam_k t}[4], F01 F02 F03 F12 F13 F23, t, pad
+
+struct GradParams {
+    LikParams L;                // candidates as for locus_loglik_kernel (cand_pidx / cand_pfac are honoured too); L.out = lnL
+    const int32_t* op_tape;     // [nops] tape slot written by a BRANCH / PUSH op, -1 otherwise
+    const int32_t* op_partner;  // [nops] for POP_MUL: tape slot of the PUSH it pops
+    int32_t ntape;
+    int64_t ncand;
+    double* tape;               // [gridDim.x][ntape][4][kGradBlock]
+    double* out_dexch;          // [ncand][6]   d lnL / d r  (AC, AG, AT, CG, CT, GT), branch lengths held fixed
+    double* out_dlogt;          // [ncand][nnodes] d lnL / d log t_b, or null
+    double* out_sum_dlogt;      // [ncand]
+};
+
+__device__ inline double lik_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
+    const LikParams& P = G.L;
+    extern __shared__ double lds[];
+    const int nn = P.nnodes;
+    double* Pm = lds;                                   // [nn][16]
+    double* EF = Pm + (size_t)nn * 16;                  // [nn][kGradEF]
+    double* gb = EF + (size_t)nn * kGradEF;             // [kGradWaves][nn]
+    double* stack = gb + (size_t)kGradWaves * nn;       // [depth][4][kGradBlock]
+    __shared__ double eig[36];
+    __shared__ double tipY[16 * 4];
+    __shared__ double red[kGradWaves * 18];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* tape = G.tape + (size_t)blockIdx.x * (size_t)G.ntape * 4 * kGradBlock + tid;
+    for (int64_t cand = blockIdx.x; cand < G.ncand; cand += gridDim.x) {
+        __syncthreads();
+        const int locus = P.cand_locus[cand];
+        const double* pi = P.models[locus].pi;
+        if (tid == 0) lik_eigen(pi, P.cand_exch + (size_t)cand * 6, eig);
+        __syncthreads();
+        const double* bl = P.blen_vecs + (size_t)P.cand_vec[cand] * nn;
+        const double bscale = P.cand_scale[cand], pfac = P.cand_pfac[cand];
+        const int pidx = P.cand_pidx[cand];
+        for (int idx = tid; idx < nn * 16; idx += kGradBlock) {
+            const int b = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
+            const double t = bl[b] * bscale * (b == pidx ? pfac : 1.0);
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s = fma(eig[4 + i * 4 + k] * exp(eig[k] * t), eig[20 + k * 4 + j], s);
+            Pm[idx] = s;
+        }
+        for (int b = tid; b < nn; b += kGradBlock) {
+            const double t = bl[b] * bscale * (b == pidx ? pfac : 1.0);
+            double e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { e[k] = exp(eig[k] * t); EF[b * kGradEF + k] = e[k]; }
+            int q = 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int l = k + 1; l < 4; ++l) {
+                    const double x = (eig[k] - eig[l]) * t;       // F_kl = t e^{lam_l t} expm1(x) / x
+                    const double r = (fabs(x) < 1e-8) ? 1.0 + 0.5 * x : expm1(x) / x;
+                    EF[b * kGradEF + q++] = t * e[l] * r;
+                }
+            EF[b * kGradEF + 10] = t;
+            EF[b * kGradEF + 11] = 0.0;
+            for (int w = 0; w < kGradWaves; ++w) gb[w * nn + b] = 0.0;
+        }
+        if (tid < 64) {  // y of a tip = U^-1 (0/1 vector of the state mask)
+            const int m = tid >> 2, k = tid & 3;
+            double s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += ((m >> j) & 1) ? eig[20 + k * 4 + j] : 0.0;
+            tipY[tid] = s;
+        }
+        __syncthreads();
+        double U[16], Ui[16], lam[4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { U[i] = eig[4 + i]; Ui[i] = eig[20 + i]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lam[k] = eig[k];
+        const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+        double total = 0.0;
+        double W[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) W[i] = 0.0;
+
+        // x = U^T abar, y given: accumulate W and the branch-length derivative of `node`
+        auto contribute = [&](int node, const double* x, const double* y) {
+            const double* ef = EF + (size_t)node * kGradEF;
+            const double e0 = ef[0], e1 = ef[1], e2 = ef[2], e3 = ef[3], t = ef[10];
+            const double f01 = ef[4], f02 = ef[5], f03 = ef[6], f12 = ef[7], f13 = ef[8], f23 = ef[9];
+            W[0] = fma(x[0] * (t * e0), y[0], W[0]);  W[1] = fma(x[0] * f01, y[1], W[1]);
+            W[2] = fma(x[0] * f02, y[2], W[2]);       W[3] = fma(x[0] * f03, y[3], W[3]);
+            W[4] = fma(x[1] * f01, y[0], W[4]);       W[5] = fma(x[1] * (t * e1), y[1], W[5]);
+            W[6] = fma(x[1] * f12, y[2], W[6]);       W[7] = fma(x[1] * f13, y[3], W[7]);
+            W[8] = fma(x[2] * f02, y[0], W[8]);       W[9] = fma(x[2] * f12, y[1], W[9]);
+            W[10] = fma(x[2] * (t * e2), y[2], W[10]); W[11] = fma(x[2] * f23, y[3], W[11]);
+            W[12] = fma(x[3] * f03, y[0], W[12]);     W[13] = fma(x[3] * f13, y[1], W[13]);
+            W[14] = fma(x[3] * f23, y[2], W[14]);     W[15] = fma(x[3] * (t * e3), y[3], W[15]);
+            double c = x[0] * (lam[0] * e0) * y[0];
+            c = fma(x[1] * (lam[1] * e1), y[1], c);
+            c = fma(x[2] * (lam[2] * e2), y[2], c);
+            c = fma(x[3] * (lam[3] * e3), y[3], c);
+            c = lik_wave_sum(c);
+            if (lane == 0) gb[wave * nn + node] += c;
+        };
+
+        for (int64_t base = lo; base < hi; base += kGradBlock) {
+            const int64_t col = base + tid;
+            const bool active = col < hi;
+            const int64_t c = active ? col : lo;
+            double acc[4] = {1.0, 1.0, 1.0, 1.0};
+            int scale = 0, sp = 0;
+            // ---------------- forward ----------------
+            for (int ip = 0; ip < P.nops; ++ip) {
+                const TreeOp op = P.ops[ip];
+                if (op.code <= OP_TIP_MUL) {
+                    unsigned m = P.states[(int64_t)op.taxon * P.ncols_total + c] & 15u;
+                    m = m ? m : 15u;
+                    const double* Pb = Pm + (size_t)P.op_node[ip] * 16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double v = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v += ((m >> j) & 1u) ? Pb[i * 4 + j] : 0.0;
+                        acc[i] *= v;
+                    }
+                } else if (op.code == OP_BRANCH) {
+                    double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) slot[i * kGradBlock] = acc[i];   // raw: the reverse sweep redoes the rescale
+                    const double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
+                    if (mx < 1e-200 && mx > 0) {
+                        int e;
+                        frexp(mx, &e);
+                        for (int i = 0; i < 4; ++i) acc[i] = ldexp(acc[i], -e);
+                        scale += e;
+                    }
+                    const double* Pb = Pm + (size_t)P.op_node[ip] * 16;
+                    double r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        r[i] = fma(Pb[i * 4 + 3], acc[3], fma(Pb[i * 4 + 2], acc[2], fma(Pb[i * 4 + 1], acc[1], Pb[i * 4] * acc[0])));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = r[i];
+                } else if (op.code == OP_PUSH) {
+                    double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { slot[i * kGradBlock] = acc[i]; acc[i] = 1.0; }
+                    ++sp;   // the value itself lives on the tape; `stack` is only the reverse sweep's adjoint stack
+                } else {
+                    --sp;
+                    const double* slot = tape + (size_t)G.op_partner[ip] * 4 * kGradBlock;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] *= slot[i * kGradBlock];
+                }
+            }
+            const double Lc = fma(pi[3], acc[3], fma(pi[2], acc[2], fma(pi[1], acc[1], pi[0] * acc[0])));
+            if (active) total += log(Lc) + (double)scale * 0.6931471805599453;
+            // ---------------- reverse ----------------
+            const double seed = active ? 1.0 / Lc : 0.0;   // padding lanes contribute exact zeros
+            double ab[4] = {pi[0] * seed, pi[1] * seed, pi[2] * seed, pi[3] * seed};
+            int asp = 0;
+            for (int ip = P.nops - 1; ip >= 0; --ip) {
+                const TreeOp op = P.ops[ip];
+                if (op.code <= OP_TIP_MUL) {
+                    unsigned m = P.states[(int64_t)op.taxon * P.ncols_total + c] & 15u;
+                    m = m ? m : 15u;
+                    const int node = P.op_node[ip];
+                    const double* Pb = Pm + (size_t)node * 16;
+                    double vb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        double v = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v += ((m >> j) & 1u) ? Pb[i * 4 + j] : 0.0;
+                        acc[i] = acc[i] / v;        // the partial before this tip was folded in
+                        vb[i] = ab[i] * acc[i];     // adjoint of the tip's message
+                        ab[i] *= v;
+                    }
+                    double x[4], y[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[k] = fma(U[12 + k], vb[3], fma(U[8 + k], vb[2], fma(U[4 + k], vb[1], U[k] * vb[0])));
+                        y[k] = tipY[m * 4 + k];
+                    }
+                    contribute(node, x, y);
+                } else if (op.code == OP_BRANCH) {
+                    const int node = P.op_node[ip];
+                    const double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+                    double a[4], as[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { a[i] = slot[i * kGradBlock]; as[i] = a[i]; }
+                    double sc = 1.0;
+                    const double mx = fmax(fmax(a[0], a[1]), fmax(a[2], a[3]));
+                    if (mx < 1e-200 && mx > 0) {
+                        int e;
+                        frexp(mx, &e);
+                        for (int i = 0; i < 4; ++i) as[i] = ldexp(a[i], -e);
+                        sc = ldexp(1.0, -e);
+                    }
+                    double x[4], y[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[k] = fma(U[12 + k], ab[3], fma(U[8 + k], ab[2], fma(U[4 + k], ab[1], U[k] * ab[0])));
+                        y[k] = fma(Ui[k * 4 + 3], as[3], fma(Ui[k * 4 + 2], as[2], fma(Ui[k * 4 + 1], as[1], Ui[k * 4] * as[0])));
+                    }
+                    contribute(node, x, y);
+                    const double* ef = EF + (size_t)node * kGradEF;
+                    const double z0 = ef[0] * x[0], z1 = ef[1] * x[1], z2 = ef[2] * x[2], z3 = ef[3] * x[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ab[j] = sc * fma(Ui[12 + j], z3, fma(Ui[8 + j], z2, fma(Ui[4 + j], z1, Ui[j] * z0)));
+                        acc[j] = a[j];
+                    }
+                } else if (op.code == OP_PUSH) {
+                    --asp;
+                    const double* as_ = stack + ((size_t)asp * 4) * kGradBlock + tid;
+                    const double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { ab[i] = as_[i * kGradBlock]; acc[i] = slot[i * kGradBlock]; }
+                } else {
+                    const double* slot = tape + (size_t)G.op_partner[ip] * 4 * kGradBlock;
+                    double* as_ = stack + ((size_t)asp * 4) * kGradBlock + tid;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double S = slot[i * kGradBlock];
+                        acc[i] = acc[i] / S;                 // the partial that was multiplied by the parked one
+                        as_[i * kGradBlock] = ab[i] * acc[i];
+                        ab[i] *= S;
+                    }
+                    ++asp;
+                }
+            }
+        }
+        // ---------------- reductions (fixed order) ----------------
+        total = lik_wave_sum(total);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) W[i] = lik_wave_sum(W[i]);
+        if (lane == 0) {
+            red[wave * 18] = total;
+            for (int i = 0; i < 16; ++i) red[wave * 18 + 1 + i] = W[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double lnl = 0, Wt[16];
+            for (int i = 0; i < 16; ++i) Wt[i] = 0;
+            for (int w = 0; w < kGradWaves; ++w) {
+                lnl += red[w * 18];
+                for (int i = 0; i < 16; ++i) Wt[i] += red[w * 18 + 1 + i];
+            }
+            P.out[cand] = lnl;
+            // dQ/dr_ij = pi_j (E_ij - E_ii) + pi_i (E_ji - E_jj)  ->  G_kl = (U_jl - U_il) (pi_j Ui_ki - pi_i Ui_kj)
+            const int pi_[6] = {0, 0, 0, 1, 1, 2}, pj_[6] = {1, 2, 3, 2, 3, 3};
+            for (int q = 0; q < 6; ++q) {
+                const int i = pi_[q], j = pj_[q];
+                double d = 0;
+                for (int k = 0; k < 4; ++k)
+                    for (int l = 0; l < 4; ++l)
+                        d += Wt[k * 4 + l] * (eig[4 + j * 4 + l] - eig[4 + i * 4 + l]) * (pi[j] * eig[20 + k * 4 + i] - pi[i] * eig[20 + k * 4 + j]);
+                G.out_dexch[cand * 6 + q] = d;
+            }
+        }
+        // d lnL / d log t_b = t_b * sum over waves; and its total
+        double part = 0.0;
+        for (int b = tid; b < nn; b += kGradBlock) {
+            double g = 0;
+            for (int w = 0; w < kGradWaves; ++w) g += gb[w * nn + b];
+            g *= EF[b * kGradEF + 10];
+            if (G.out_dlogt) G.out_dlogt[cand * nn + b] = g;
+            part += g;
+        }
+        part = lik_wave_sum(part);
+        __syncthreads();   // red[] was read by thread 0 above
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0;
+            for (int w = 0; w < kGradWaves; ++w) s += red[w];
+            G.out_sum_dlogt[cand] = s;
+        }
+    }
 }
 
 }  // namespace tphip

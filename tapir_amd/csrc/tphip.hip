@@ -85,13 +85,16 @@ struct tphip_plan {
     DevBuf<TreeOp> d_ops;
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
-    DevBuf<int32_t> d_tip_taxon, d_op_node;
+    DevBuf<int32_t> d_tip_taxon, d_op_node, d_op_tape, d_op_partner;
+    double* d_tape = nullptr;   // reverse-mode tape of locus_grad_kernel, grown on demand
+    size_t tape_bytes = 0;
     int32_t nnodes = 0;
     int32_t nwords = 0;
     DevBuf<int32_t> d_site_chunk_locus, d_site_chunk_index, d_pi_chunk_locus, d_pi_chunk_index, d_times, d_intervals;
     DevBuf<unsigned long long> d_evals;
     // workspace layout (bytes)
     size_t ws_work_cols = 0, ws_work_count = 0, ws_work_prefix = 0, ws_partial = 0, ws_packed = 0, ws_total = 0;
+    int32_t num_cus = 256;
     int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
     int32_t site_persistent = 1;
     // profiling
@@ -121,6 +124,8 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_locus_pichunk_offsets.release(); plan->d_site_chunk_locus.release(); plan->d_site_chunk_index.release();
     plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
     plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
+    plan->d_op_tape.release(); plan->d_op_partner.release();
+    if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TPHIP_OK;
@@ -204,6 +209,8 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->nwords = (int32_t)((tip_taxon.size() + 7) / 8);
     if (e == hipSuccess) e = p->d_tip_taxon.upload(tip_taxon);
     if (e == hipSuccess) e = p->d_op_node.upload(p->prog.op_node);
+    if (e == hipSuccess) e = p->d_op_tape.upload(p->prog.op_tape);
+    if (e == hipSuccess) e = p->d_op_partner.upload(p->prog.op_partner);
     p->nnodes = d->nnodes;
     if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
     if (e == hipSuccess) e = p->d_offsets.upload(p->h_offsets);
@@ -245,6 +252,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         else oe = occ(site_rate_kernel<0>);
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         p->site_waves = per_cu * prop.multiProcessorCount;
+        p->num_cus = prop.multiProcessorCount;
         // Small batches (an equal share would be under ~1000 columns) run one workgroup per locus-aligned
         // slice instead: cutting a small locus in two doubles its prologue and drain (measured on C2).
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
@@ -518,6 +526,48 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
     return TPHIP_OK;
 }
 
+int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand, const int32_t* d_cand_locus,
+                             const double* d_cand_exch, const double* d_blen_vecs, const int32_t* d_cand_vec,
+                             const double* d_cand_scale, const int32_t* d_cand_pidx, const double* d_cand_pfac, double* d_lnl,
+                             double* d_dexch, double* d_dlogt, double* d_sum_dlogt, void* stream) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (ncand < 0 || (ncand && (!d_states || !d_cand_locus || !d_cand_exch || !d_blen_vecs || !d_cand_vec || !d_cand_scale ||
+                                !d_cand_pidx || !d_cand_pfac || !d_lnl || !d_dexch || !d_sum_dlogt)))
+        return fail(TPHIP_ERR_INVALID, "null device pointer");
+    if (ncand == 0) return TPHIP_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    GradParams G;
+    LikParams& L = G.L;
+    L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;
+    L.ops = p->d_ops.p; L.op_node = p->d_op_node.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes;
+    L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
+    L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
+    L.cand_pfac = d_cand_pfac; L.out = d_lnl;
+    G.op_tape = p->d_op_tape.p; G.op_partner = p->d_op_partner.p; G.ntape = p->prog.ntape; G.ncand = ncand;
+    G.out_dexch = d_dexch; G.out_dlogt = d_dlogt; G.out_sum_dlogt = d_sum_dlogt;
+    const size_t lds = ((size_t)p->nnodes * (16 + kGradEF + kGradWaves) + (size_t)p->prog.stack_depth * 4 * kGradBlock) * sizeof(double);
+    if (lds > 150 * 1024) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-gradient kernel's LDS tables");
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)locus_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    // resident workgroups loop over the candidates; each owns one tape
+    int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds + 1024, 1)));
+    if (const char* env = getenv("TPHIP_GRAD_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(env));
+    const int64_t grid = std::min<int64_t>(ncand, (int64_t)p->num_cus * blocks_per_cu);
+    const size_t need = (size_t)grid * (size_t)std::max(1, p->prog.ntape) * 4 * kGradBlock * sizeof(double);
+    if (need > p->tape_bytes) {
+        if (p->d_tape) { HIP_TRY(hipFree(p->d_tape)); p->d_tape = nullptr; p->tape_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&p->d_tape, need));
+        p->tape_bytes = need;
+    }
+    G.tape = p->d_tape;
+    locus_grad_kernel<<<dim3((unsigned)grid), dim3(kGradBlock), lds, (hipStream_t)stream>>>(G);
+    HIP_TRY(hipGetLastError());
+    return TPHIP_OK;
+}
+
 int tphip_state_histogram_dev(int32_t device, const uint8_t* d_states, int64_t ncols_total, int32_t ntaxa,
                               const int64_t* d_locus_offsets, int64_t nloci, int64_t* d_hist, void* stream) {
     if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
@@ -724,6 +774,65 @@ int tphip_locus_loglik(tphip_plan* p, const uint8_t* states, void** d_states_cac
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
+}
+
+int tphip_locus_gradient(tphip_plan* p, const uint8_t* states, void** d_states_cache, int64_t nvec, const double* blen_vecs,
+                         int64_t ncand, const int32_t* cand_locus, const double* cand_exch, const int32_t* cand_vec,
+                         const double* cand_scale, const int32_t* cand_pidx, const double* cand_pfac, double* lnl,
+                         double* dexch, double* dlogt, double* sum_dlogt) {
+    if (!p || !states || ncand < 0 || nvec < 0 ||
+        (ncand && (!blen_vecs || !cand_locus || !cand_exch || !cand_vec || !cand_scale || !cand_pidx || !cand_pfac || !lnl ||
+                   !dexch || !sum_dlogt)))
+        return fail(TPHIP_ERR_INVALID, "null argument");
+    if (ncand == 0) return TPHIP_OK;
+    for (int64_t c = 0; c < ncand; ++c) {
+        if (cand_locus[c] < 0 || cand_locus[c] >= p->nloci) return fail(TPHIP_ERR_INVALID, "cand_locus out of range");
+        if (cand_vec[c] < 0 || cand_vec[c] >= nvec) return fail(TPHIP_ERR_INVALID, "cand_vec out of range");
+        if (cand_pidx[c] >= p->nnodes) return fail(TPHIP_ERR_INVALID, "cand_pidx out of range");
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    Scratch S;
+    const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
+    uint8_t* d_s = d_states_cache ? (uint8_t*)*d_states_cache : nullptr;
+    if (!d_s) {
+        if (d_states_cache) {
+            HIP_TRY(hipMalloc((void**)&d_s, nb ? nb : 1));
+            *d_states_cache = d_s;
+        } else {
+            d_s = S.get<uint8_t>(nb);
+            if (!d_s) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+        }
+        HIP_TRY(hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice));
+    }
+    const size_t n = (size_t)ncand, nn = (size_t)p->nnodes;
+    int32_t* d_l = S.get<int32_t>(n);
+    double* d_e = S.get<double>(n * 6);
+    double* d_b = S.get<double>((size_t)nvec * nn);
+    int32_t* d_v = S.get<int32_t>(n);
+    double* d_sc = S.get<double>(n);
+    int32_t* d_pi = S.get<int32_t>(n);
+    double* d_pf = S.get<double>(n);
+    double* d_o = S.get<double>(n);
+    double* d_de = S.get<double>(n * 6);
+    double* d_dt = dlogt ? S.get<double>(n * nn) : nullptr;
+    double* d_st = S.get<double>(n);
+    if (!d_l || !d_e || !d_b || !d_v || !d_sc || !d_pi || !d_pf || !d_o || !d_de || !d_st || (dlogt && !d_dt))
+        return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_l, cand_locus, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_e, cand_exch, sizeof(double) * n * 6, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b, blen_vecs, sizeof(double) * (size_t)nvec * nn, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_v, cand_vec, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_sc, cand_scale, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pi, cand_pidx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pf, cand_pfac, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = tphip_locus_gradient_dev(p, d_s, ncand, d_l, d_e, d_b, d_v, d_sc, d_pi, d_pf, d_o, d_de, d_dt, d_st, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(lnl, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dexch, d_de, sizeof(double) * n * 6, hipMemcpyDeviceToHost));
+    if (dlogt) HIP_TRY(hipMemcpy(dlogt, d_dt, sizeof(double) * n * nn, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sum_dlogt, d_st, sizeof(double) * n, hipMemcpyDeviceToHost));
     return TPHIP_OK;
 }
 

@@ -35,6 +35,9 @@ static_assert(sizeof(TreeOp) == 16, "TreeOp is read with one s_load_dwordx4");
 struct TreeProgram {
     std::vector<TreeOp> ops;
     std::vector<int32_t> op_node;  // tree node whose branch a TIP_* / BRANCH op climbs (-1 for PUSH / POP_MUL)
+    std::vector<int32_t> op_tape;     // reverse-mode tape slot written by a BRANCH / PUSH op (-1 otherwise)
+    std::vector<int32_t> op_partner;  // POP_MUL: tape slot of the PUSH it pops (-1 otherwise)
+    int32_t ntape = 0;
     int32_t stack_depth = 0;   // LDS slots per lane
     double chrono_length = 0;  // sum of all branch lengths (bf:1006-1013)
     int32_t nleaves = 0;
@@ -122,6 +125,25 @@ inline std::string build_tree_program(int32_t ntaxa, int32_t nnodes, const int32
             }
         }
     }
+    // tape slots for the gradient kernel (locus_grad_kernel)
+    out->op_tape.assign(out->ops.size(), -1);
+    out->op_partner.assign(out->ops.size(), -1);
+    out->ntape = 0;
+    std::vector<int32_t> pushed;
+    for (size_t i = 0; i < out->ops.size(); ++i) {
+        const int32_t code = out->ops[i].code;
+        if (code == OP_BRANCH) {
+            out->op_tape[i] = out->ntape++;
+        } else if (code == OP_PUSH) {
+            out->op_tape[i] = out->ntape++;
+            pushed.push_back(out->op_tape[i]);
+        } else if (code == OP_POP_MUL) {
+            if (pushed.empty()) return "internal error: POP_MUL without PUSH";
+            out->op_partner[i] = pushed.back();
+            pushed.pop_back();
+        }
+    }
+    if (!pushed.empty()) return "internal error: unbalanced PUSH";
     return "";
 }
 

@@ -51,6 +51,7 @@ SYMBOLS = [
     ("tphip_townsend_pi_dense_dev", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     ("tphip_quad_townsend_dev", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp, _vp]),
     ("tphip_locus_loglik_dev", ctypes.c_int, [_vp, _vp, _i64] + [_vp] * 9),
+    ("tphip_locus_gradient_dev", ctypes.c_int, [_vp, _vp, _i64] + [_vp] * 12),
     ("tphip_state_histogram_dev", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     ("tphip_profile_enable", ctypes.c_int, [_vp, _i32]),
     ("tphip_profile_read", ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_f64), ctypes.POINTER(_i64), _i32]),
@@ -63,6 +64,7 @@ SYMBOLS = [
     ("tphip_state_histogram", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     ("tphip_eval_columns", ctypes.c_int, [_vp] * 6),
     ("tphip_locus_loglik", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 7),
+    ("tphip_locus_gradient", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 10),
     ("tphip_free_device", ctypes.c_int, [_vp, _vp]),
 ]
 
@@ -225,6 +227,29 @@ class Plan:
                                             ce.ctypes.data, cv.ctypes.data, cs.ctypes.data, ci.ctypes.data, cf.ctypes.data,
                                             out.ctypes.data))
         return out
+
+    def locus_gradient(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
+                       cand_pfac=None, cache=None, per_branch=True):
+        """locus_loglik plus its derivatives (tphip_locus_gradient): returns (lnl[n], dexch[n, 6], dlogt[n, nnodes] or
+        None, sum_dlogt[n]); dexch holds branch lengths fixed, dlogt is d lnL / d log t_b."""
+        states = _np(states, np.uint8)
+        bv = _np(blen_vecs, np.float64)
+        bv = bv.reshape(-1, bv.shape[-1])
+        cl = _np(cand_locus, np.int32).reshape(-1)
+        n = len(cl)
+        ce = _np(cand_exch, np.float64).reshape(n, 6)
+        cv = _np(np.arange(n) if cand_vec is None else cand_vec, np.int32).reshape(n)
+        cs = _np(np.ones(n) if cand_scale is None else cand_scale, np.float64).reshape(n)
+        ci = _np(np.full(n, -1) if cand_pidx is None else cand_pidx, np.int32).reshape(n)
+        cf = _np(np.ones(n) if cand_pfac is None else cand_pfac, np.float64).reshape(n)
+        lnl, dex, st = np.empty(n), np.empty((n, 6)), np.empty(n)
+        dlt = np.empty((n, bv.shape[1])) if per_branch else None
+        ref = ctypes.byref(cache.ptr) if cache is not None else None
+        _check(self._lib.tphip_locus_gradient(self._h, states.ctypes.data, ref, bv.shape[0], bv.ctypes.data, n, cl.ctypes.data,
+                                              ce.ctypes.data, cv.ctypes.data, cs.ctypes.data, ci.ctypes.data, cf.ctypes.data,
+                                              lnl.ctypes.data, dex.ctypes.data, dlt.ctypes.data if per_branch else None,
+                                              st.ctypes.data))
+        return lnl, dex, dlt, st
 
     def device_cache(self):
         """Holder that keeps the alignment on the device across locus_loglik calls; release() frees it."""

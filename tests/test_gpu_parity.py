@@ -434,3 +434,86 @@ def test_locus_loglik_vs_oracle(oracle):
             ref = oracle.locus_loglik(st[:, off[l]:off[l + 1]], pin["parent"], cb[c], pin["leaf"], d["pi"][l], ce[c])
             assert abs(got[c] - ref) < 1e-9 * abs(ref), (c, got[c], ref)
         plan.close()
+
+
+def _fd_gradient(oracle, st, parent, leaf, pi, exch, blen, h=1e-5):
+    """Central differences of the oracle's log-likelihood w.r.t. the six exchangeabilities and every log branch
+    length (the independent check of the reverse-mode kernel)."""
+    parent = np.asarray(parent)
+    f = lambda e, b: oracle.locus_loglik(st, parent, b, leaf, pi, e)
+    dex = np.zeros(6)
+    for q in range(6):
+        ep, em = exch.copy(), exch.copy()
+        ep[q] *= 1 + h
+        em[q] *= 1 - h
+        dex[q] = (f(ep, blen) - f(em, blen)) / (2 * h * exch[q])
+    dlt = np.zeros(len(parent))
+    for b in np.flatnonzero(parent >= 0):
+        bp, bm = blen.copy(), blen.copy()
+        bp[b] *= np.exp(h)
+        bm[b] *= np.exp(-h)
+        dlt[b] = (f(exch, bp) - f(exch, bm)) / (2 * h)
+    return dex, dlt
+
+
+def test_locus_gradient_vs_oracle_finite_differences(oracle):
+    """Reverse-mode gradient kernel: lnL bit-compatible with the value kernel, derivatives w.r.t. all six
+    exchangeabilities and every branch length against central differences of the ORACLE's likelihood.
+    Covers ambiguity codes, ragged loci, more candidates than resident workgroups' first wave, scaled and
+    perturbed shared vectors, equal eigenvalues (all rates 1: the F_kl limit) and a polytomy."""
+    engine = _engine()
+    from tapir_amd import synth
+    rng = np.random.default_rng(17)
+    for ntaxa, nloci, ncols in ((9, 4, 211), (40, 2, 300)):
+        d = synth.simulate(nloci, ncols, ntaxa, 60 + ntaxa, rate_mean=0.01)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        st = d["states"].numpy().copy()
+        st[rng.random(st.shape) < 0.03] = 5
+        off = d["locus_offsets"].copy()
+        off[1] -= 5
+        plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, d["pi"], d["exch"], 3, [1], [[0, 1]])
+        nn = len(pin["parent"])
+        ncand = 11
+        cl = rng.integers(0, nloci, ncand)
+        ce = np.exp(rng.normal(0, 0.5, (ncand, 6)))
+        ce[0] = 1.0  # Jukes-Cantor-like exchangeabilities: three equal eigenvalues
+        cb = pin["blen"][None, :] * np.exp(rng.normal(0, 0.7, (ncand, nn)))
+        cs = np.exp(rng.normal(0, 0.3, ncand))
+        ci = rng.integers(-1, nn - 1, ncand)
+        cf = np.exp(rng.normal(0, 0.2, ncand))
+        cache = plan.device_cache()
+        val = plan.locus_loglik(st, cb, cl, ce, None, cs, ci, cf, cache=cache)
+        lnl, dex, dlt, sdl = plan.locus_gradient(st, cb, cl, ce, None, cs, ci, cf, cache=cache)
+        lnl2, dex2, none, sdl2 = plan.locus_gradient(st, cb, cl, ce, None, cs, ci, cf, cache=cache, per_branch=False)
+        cache.release()
+        assert none is None and np.array_equal(lnl, lnl2) and np.array_equal(dex, dex2) and np.array_equal(sdl, sdl2)
+        assert np.max(np.abs(lnl - val) / np.abs(val)) < 1e-13
+        assert np.max(np.abs(dlt.sum(1) - sdl)) < 1e-9 * np.abs(dlt).sum(1).max()
+        for c in range(ncand):
+            l = int(cl[c])
+            b = cb[c] * cs[c]
+            if ci[c] >= 0:
+                b[ci[c]] *= cf[c]
+            rdex, rdlt = _fd_gradient(oracle, st[:, off[l]:off[l + 1]], pin["parent"], pin["leaf"], d["pi"][l], ce[c], b)
+            tol = 2e-6 * max(1.0, np.abs(rdex).max(), np.abs(rdlt).max())
+            assert np.max(np.abs(dex[c] - rdex)) < tol, (c, dex[c], rdex)
+            assert np.max(np.abs(dlt[c] - rdlt)) < tol, (c, np.abs(dlt[c] - rdlt).max())
+        plan.close()
+    # a polytomy (three internal children under the root) and a 2-taxon tree
+    from tapir_amd import newick
+    for text in ("((a:1,b:2):1,(c:1,d:1.5):2,(e:0.5,f:1):1,g:3);", "(a:1,b:2);"):
+        root = newick.parse(text)
+        names = [n.name for n in newick.leaves(root)]
+        parent, blen, leaf = newick.to_arrays(root, names)
+        st = rng.choice(np.array([1, 2, 4, 8, 15, 5], dtype=np.uint8), size=(len(names), 97))
+        pi = np.array([0.1, 0.2, 0.3, 0.4])
+        exch = np.array([0.7, 1.0, 1.9, 0.4, 2.5, 1.1])
+        plan = engine.Plan(len(names), parent, blen, leaf, [0, 97], [pi], [exch], 3, [1], [[0, 1]])
+        b = np.asarray(blen) * 0.1
+        lnl, dex, dlt, sdl = plan.locus_gradient(st, b[None, :], [0], [exch])
+        ref = oracle.locus_loglik(st, parent, b, leaf, pi, exch)
+        rdex, rdlt = _fd_gradient(oracle, st, parent, leaf, pi, exch, b)
+        assert abs(lnl[0] - ref) < 1e-10 * abs(ref)
+        tol = 2e-6 * max(1.0, np.abs(rdex).max(), np.abs(rdlt).max())
+        assert np.max(np.abs(dex[0] - rdex)) < tol and np.max(np.abs(dlt[0] - rdlt)) < tol
+        plan.close()
