@@ -204,6 +204,16 @@ int tphip_quad_townsend(int32_t device, const double *rates, int64_t n, double a
                         double *integral, double *abserr);
 int tphip_state_histogram(int32_t device, const uint8_t *states, int64_t ncols_total, int32_t ntaxa,
                           const int64_t *locus_offsets, int64_t nloci, int64_t *hist);
+/* Unique site patterns per locus (HyPhy: GetDataInfo(dupInfo, filteredData), models_and_rates.bf:960-963; its stage 1
+ * sums pattern likelihoods weighted by counts and its stage 2 fits one rate per pattern).  Columns of a locus that are
+ * identical after normalising the state masks (0 -> 15) collapse into one pattern.  Outputs: out_states
+ * [ntaxa][*out_npatterns] taxon-major (the buffer must hold ntaxa * ncols_total bytes), out_offsets [nloci+1] pattern
+ * offsets per locus, out_weight [*out_npatterns] column counts (buffer of ncols_total doubles), out_map [ncols_total]
+ * column -> pattern index (may be NULL).  Patterns of a locus are in hash order, deterministic for given input.
+ * Exact: equality is decided on the full columns, hashes only group candidates.  Plan-less, host pointers. */
+int tphip_compress_columns(int32_t device, const uint8_t *states, int64_t ncols_total, int32_t ntaxa,
+                           const int64_t *locus_offsets, int64_t nloci, uint8_t *out_states, int64_t *out_offsets,
+                           double *out_weight, int64_t *out_map, int64_t *out_npatterns);
 /* host-pointer twin of tphip_locus_loglik_dev; d_states_cache may keep the alignment on the device between calls:
  * pass the address of a NULL void* the first time and free it with tphip_free_device when done (NULL = copy the
  * alignment on every call) */
@@ -217,6 +227,10 @@ int tphip_locus_gradient(tphip_plan *plan, const uint8_t *states, void **d_state
                          const int32_t *cand_vec, const double *cand_scale, const int32_t *cand_pidx,
                          const double *cand_pfac, double *lnl, double *dexch, double *dlogt, double *sum_dlogt);
 int tphip_free_device(tphip_plan *plan, void *d_ptr);
+/* Column multiplicities [ncols] (host) for tphip_locus_loglik / tphip_locus_gradient of this plan: the plan's columns
+ * are then site patterns (tphip_compress_columns) and every pattern's log-likelihood counts weight times.
+ * NULL removes them.  The site-rate path ignores them. */
+int tphip_plan_set_column_weights(tphip_plan *plan, const double *weights);
 
 /* Diagnostic (tests): log L and its first two derivatives with respect to u = log(siteRate) for every
  * column at a caller-chosen u[ncols]; no classification, no optimiser.  Host pointers. */

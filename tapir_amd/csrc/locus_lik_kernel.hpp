@@ -29,6 +29,7 @@ struct LikParams {
     const uint8_t* states;         // [ntaxa][ncols_total]
     int64_t ncols_total;
     const int64_t* locus_offsets;  // [nloci+1]
+    const double* col_weight;      // [ncols_total] multiplicity of each column (site-pattern counts), null = 1
     const LocusModel* models;      // [nloci] (only pi is used)
     const TreeOp* ops;             // shared traversal program
     const int32_t* op_node;        // [nops] node whose branch the op climbs
@@ -45,8 +46,33 @@ struct LikParams {
     const double* cand_scale;      // [ncand]
     const int32_t* cand_pidx;      // [ncand] node whose branch is perturbed, -1 for none
     const double* cand_pfac;       // [ncand]
-    double* out;                   // [ncand] sum over columns of log L
+    double* out;                   // [ncand * nsplit] sum over columns of log L (partials when nsplit > 1)
+    // Column split: a candidate's columns are cut into nsplit slices (multiples of the block size), one work item
+    // each, so that a handful of candidates on long loci still fills the device; slice sums are added up in
+    // fixed order by split_sum_kernel.
+    int32_t nsplit;
 };
+
+// [lo, hi) of slice s of a locus spanning [llo, lhi)
+__device__ inline void split_range(int64_t llo, int64_t lhi, int nsplit, int s, int block, int64_t* lo, int64_t* hi) {
+    const int64_t len = lhi - llo;
+    const int64_t per = ((len + nsplit - 1) / nsplit + block - 1) / block * block;
+    const int64_t a = llo + (int64_t)s * per;
+    *lo = a < lhi ? a : lhi;
+    *hi = (a + per) < lhi ? (a + per) : lhi;
+    if (*hi < *lo) *hi = *lo;
+}
+
+// out[c][k] = sum_s part[c][s][k], s ascending
+__global__ void split_sum_kernel(const double* part, double* out, int64_t ncand, int nsplit, int width) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand * width) return;
+    const int64_t c = i / width;
+    const int k = (int)(i % width);
+    double s = 0;
+    for (int j = 0; j < nsplit; ++j) s += part[((size_t)c * nsplit + j) * width + k];
+    out[i] = s;
+}
 
 // Eigen-system of Q = R o pi for one candidate (single thread): eig = lam[4], U[16] (row-major, columns are right
 // eigenvectors), Ui[16] = U^-1.  Symmetrised by sqrt(pi) and diagonalised with cyclic Jacobi sweeps.
@@ -88,8 +114,14 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
     double* stack = Pm + (size_t)P.nnodes * 16;         // [depth][4][kLikBlock]
     __shared__ double eig[4 + 16 + 16];                 // lam[4], U[16], Ui[16]
     __shared__ double red[kLikBlock / 64];
-    const int cand = blockIdx.x;
+    const int64_t cand = blockIdx.x / P.nsplit;
     const int locus = P.cand_locus[cand];
+    int64_t lo, hi;
+    split_range(P.locus_offsets[locus], P.locus_offsets[locus + 1], P.nsplit, (int)(blockIdx.x % P.nsplit), kLikBlock, &lo, &hi);
+    if (lo >= hi) {   // empty slice (uniform for the block)
+        if (threadIdx.x == 0) P.out[blockIdx.x] = 0.0;
+        return;
+    }
     const double* pi = P.models[locus].pi;
     if (threadIdx.x == 0) lik_eigen(pi, P.cand_exch + (size_t)cand * 6, eig);
     __syncthreads();
@@ -106,7 +138,6 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
         Pm[idx] = s;
     }
     __syncthreads();
-    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
     double total = 0.0;
     for (int64_t base = lo; base < hi; base += kLikBlock) {   // uniform trip count: every thread meets the LDS stack
         const int64_t col = base + threadIdx.x;
@@ -155,14 +186,17 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
             }
         }
         const double L = fma(pi[3], acc[3], fma(pi[2], acc[2], fma(pi[1], acc[1], pi[0] * acc[0])));
-        if (active) total += log(L) + (double)scale * 0.6931471805599453;
+        if (active) {
+            const double w = P.col_weight ? P.col_weight[c] : 1.0;
+            total = fma(w, log(L) + (double)scale * 0.6931471805599453, total);
+        }
     }
     // fixed-order block sum
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = total;
     __syncthreads();
-    if (threadIdx.x == 0) P.out[cand] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) P.out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 // ---- value + gradient --------------------------------------------------------------------------------------
@@ -195,9 +229,10 @@ struct GradParams {
     int32_t ntape;
     int64_t ncand;
     double* tape;               // [gridDim.x][ntape][4][kGradBlock]
-    double* out_dexch;          // [ncand][6]   d lnL / d r  (AC, AG, AT, CG, CT, GT), branch lengths held fixed
-    double* out_dlogt;          // [ncand][nnodes] d lnL / d log t_b, or null
-    double* out_sum_dlogt;      // [ncand]
+    // outputs are indexed by work item = cand * nsplit + slice (partials when nsplit > 1)
+    double* out_dexch;          // [items][6]   d lnL / d r  (AC, AG, AT, CG, CT, GT), branch lengths held fixed
+    double* out_dlogt;          // [items][nnodes] d lnL / d log t_b, or null
+    double* out_sum_dlogt;      // [items]
 };
 
 __device__ inline double lik_wave_sum(double v) {
@@ -219,9 +254,19 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
     __shared__ double red[kGradWaves * 18];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* tape = G.tape + (size_t)blockIdx.x * (size_t)G.ntape * 4 * kGradBlock + tid;
-    for (int64_t cand = blockIdx.x; cand < G.ncand; cand += gridDim.x) {
+    const int64_t nitems = G.ncand * P.nsplit;
+    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         __syncthreads();
+        const int64_t cand = item / P.nsplit;
         const int locus = P.cand_locus[cand];
+        int64_t lo, hi;
+        split_range(P.locus_offsets[locus], P.locus_offsets[locus + 1], P.nsplit, (int)(item % P.nsplit), kGradBlock, &lo, &hi);
+        if (lo >= hi) {   // empty slice (uniform for the block): zero partials
+            if (tid == 0) { P.out[item] = 0.0; G.out_sum_dlogt[item] = 0.0; }
+            if (tid < 6) G.out_dexch[item * 6 + tid] = 0.0;
+            if (G.out_dlogt) for (int b = tid; b < nn; b += kGradBlock) G.out_dlogt[item * nn + b] = 0.0;
+            continue;
+        }
         const double* pi = P.models[locus].pi;
         if (tid == 0) lik_eigen(pi, P.cand_exch + (size_t)cand * 6, eig);
         __syncthreads();
@@ -267,7 +312,6 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
         for (int i = 0; i < 16; ++i) { U[i] = eig[4 + i]; Ui[i] = eig[20 + i]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) lam[k] = eig[k];
-        const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
         double total = 0.0;
         double W[16];
 #pragma unroll
@@ -345,9 +389,10 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
                 }
             }
             const double Lc = fma(pi[3], acc[3], fma(pi[2], acc[2], fma(pi[1], acc[1], pi[0] * acc[0])));
-            if (active) total += log(Lc) + (double)scale * 0.6931471805599453;
+            const double cw = active ? (P.col_weight ? P.col_weight[c] : 1.0) : 0.0;
+            total = fma(cw, log(Lc) + (double)scale * 0.6931471805599453, total);
             // ---------------- reverse ----------------
-            const double seed = active ? 1.0 / Lc : 0.0;   // padding lanes contribute exact zeros
+            const double seed = cw / Lc;   // padding lanes contribute exact zeros
             double ab[4] = {pi[0] * seed, pi[1] * seed, pi[2] * seed, pi[3] * seed};
             int asp = 0;
             for (int ip = P.nops - 1; ip >= 0; --ip) {
@@ -438,7 +483,7 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
                 lnl += red[w * 18];
                 for (int i = 0; i < 16; ++i) Wt[i] += red[w * 18 + 1 + i];
             }
-            P.out[cand] = lnl;
+            P.out[item] = lnl;
             // dQ/dr_ij = pi_j (E_ij - E_ii) + pi_i (E_ji - E_jj)  ->  G_kl = (U_jl - U_il) (pi_j Ui_ki - pi_i Ui_kj)
             const int pi_[6] = {0, 0, 0, 1, 1, 2}, pj_[6] = {1, 2, 3, 2, 3, 3};
             for (int q = 0; q < 6; ++q) {
@@ -447,7 +492,7 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
                 for (int k = 0; k < 4; ++k)
                     for (int l = 0; l < 4; ++l)
                         d += Wt[k * 4 + l] * (eig[4 + j * 4 + l] - eig[4 + i * 4 + l]) * (pi[j] * eig[20 + k * 4 + i] - pi[i] * eig[20 + k * 4 + j]);
-                G.out_dexch[cand * 6 + q] = d;
+                G.out_dexch[item * 6 + q] = d;
             }
         }
         // d lnL / d log t_b = t_b * sum over waves; and its total
@@ -456,7 +501,7 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
             double g = 0;
             for (int w = 0; w < kGradWaves; ++w) g += gb[w * nn + b];
             g *= EF[b * kGradEF + 10];
-            if (G.out_dlogt) G.out_dlogt[cand * nn + b] = g;
+            if (G.out_dlogt) G.out_dlogt[item * nn + b] = g;
             part += g;
         }
         part = lik_wave_sum(part);
@@ -466,7 +511,7 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
         if (tid == 0) {
             double s = 0;
             for (int w = 0; w < kGradWaves; ++w) s += red[w];
-            G.out_sum_dlogt[cand] = s;
+            G.out_sum_dlogt[item] = s;
         }
     }
 }

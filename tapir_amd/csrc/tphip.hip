@@ -12,6 +12,8 @@
 
 #include "gtr_model.hpp"
 #include "locus_lik_kernel.hpp"
+#include "pattern_kernels.hpp"
+#include <hipcub/hipcub.hpp>
 #include "pi_kernels.hpp"
 #include "site_rate_kernel.hpp"
 #include "tphip.h"
@@ -88,6 +90,10 @@ struct tphip_plan {
     DevBuf<int32_t> d_tip_taxon, d_op_node, d_op_tape, d_op_partner;
     double* d_tape = nullptr;   // reverse-mode tape of locus_grad_kernel, grown on demand
     size_t tape_bytes = 0;
+    double* d_col_weight = nullptr;  // optional column multiplicities for the locus likelihood / gradient kernels
+    double* d_part = nullptr;   // per-slice partial sums of the locus likelihood / gradient kernels, grown on demand
+    size_t part_bytes = 0;
+    int64_t max_locus_cols = 0;
     int32_t nnodes = 0;
     int32_t nwords = 0;
     DevBuf<int32_t> d_site_chunk_locus, d_site_chunk_index, d_pi_chunk_locus, d_pi_chunk_index, d_times, d_intervals;
@@ -126,6 +132,8 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
     plan->d_op_tape.release(); plan->d_op_partner.release();
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
+    if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
+    if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TPHIP_OK;
@@ -175,6 +183,8 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     const size_t lds_bytes = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     if (lds_bytes > 160 * 1024) { delete p; return fail(TPHIP_ERR_INVALID, "tree needs a deeper LDS stack than 160 KiB allows"); }
     p->h_offsets.assign(d->locus_offsets, d->locus_offsets + d->nloci + 1);
+    for (int64_t l = 0; l < d->nloci; ++l)
+        p->max_locus_cols = std::max<int64_t>(p->max_locus_cols, d->locus_offsets[l + 1] - d->locus_offsets[l]);
 
     // chunk tables: work slices for the optimiser, 1024-column chunks for classification and PI.
     // A slice is what one wave works through with lane refill: long enough to amortise the drain at its end,
@@ -492,6 +502,25 @@ int tphip_quad_townsend_dev(int32_t device, const double* d_rates, int64_t n, do
     return TPHIP_OK;
 }
 
+// Slices per candidate for the locus likelihood / gradient kernels: enough work items to fill the device even when
+// only a few candidates are in flight (the general model's one point per locus), never more than a locus has blocks.
+static int lik_nsplit(const tphip_plan* p, int64_t ncand, int block) {
+    if (const char* env = getenv("TPHIP_LIK_NSPLIT")) return std::max(1, atoi(env));
+    const int64_t target = (int64_t)p->num_cus * 8;
+    int64_t ns = (target + ncand - 1) / std::max<int64_t>(ncand, 1);
+    const int64_t max_blocks = std::max<int64_t>(1, (p->max_locus_cols + block - 1) / block);
+    ns = std::min(ns, max_blocks);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(ns, 4096));
+}
+
+static int grow_part(tphip_plan* p, size_t need) {
+    if (need <= p->part_bytes) return TPHIP_OK;
+    if (p->d_part) { HIP_TRY(hipFree(p->d_part)); p->d_part = nullptr; p->part_bytes = 0; }
+    HIP_TRY(hipMalloc((void**)&p->d_part, need));
+    p->part_bytes = need;
+    return TPHIP_OK;
+}
+
 int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand, const int32_t* d_cand_locus,
                            const double* d_cand_exch, const double* d_blen_vecs, const int32_t* d_cand_vec,
                            const double* d_cand_scale, const int32_t* d_cand_pidx, const double* d_cand_pfac, double* d_out,
@@ -504,6 +533,7 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
     HIP_TRY(hipSetDevice(p->device));
     LikParams L;
     L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;
+    L.col_weight = p->d_col_weight;
     L.ops = p->d_ops.p; L.op_node = p->d_op_node.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes;
     L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
@@ -515,14 +545,26 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
         HIP_TRY(hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    for (int64_t done = 0; done < ncand; done += (int64_t)1 << 30) {  // grid.x limit
-        const int64_t n = std::min<int64_t>(ncand - done, (int64_t)1 << 30);
+    const int nsplit = lik_nsplit(p, ncand, kLikBlock);
+    L.nsplit = nsplit;
+    if (nsplit > 1) {
+        int rc = grow_part(p, (size_t)ncand * nsplit * sizeof(double));
+        if (rc) return rc;
+        L.out = p->d_part;
+    }
+    const int64_t per_launch = std::max<int64_t>(1, ((int64_t)1 << 30) / nsplit);   // grid.x limit
+    for (int64_t done = 0; done < ncand; done += per_launch) {
+        const int64_t n = std::min<int64_t>(ncand - done, per_launch);
         LikParams Q = L;
         Q.cand_locus += done; Q.cand_exch += done * 6; Q.cand_vec += done; Q.cand_scale += done; Q.cand_pidx += done;
-        Q.cand_pfac += done; Q.out += done;
-        locus_loglik_kernel<<<dim3((unsigned)n), dim3(kLikBlock), lds, (hipStream_t)stream>>>(Q);
+        Q.cand_pfac += done; Q.out += done * nsplit;
+        locus_loglik_kernel<<<dim3((unsigned)(n * nsplit)), dim3(kLikBlock), lds, (hipStream_t)stream>>>(Q);
     }
     HIP_TRY(hipGetLastError());
+    if (nsplit > 1) {
+        split_sum_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(p->d_part, d_out, ncand, nsplit, 1);
+        HIP_TRY(hipGetLastError());
+    }
     return TPHIP_OK;
 }
 
@@ -539,6 +581,7 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     GradParams G;
     LikParams& L = G.L;
     L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;
+    L.col_weight = p->d_col_weight;
     L.ops = p->d_ops.p; L.op_node = p->d_op_node.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes;
     L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
@@ -555,7 +598,18 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     // resident workgroups loop over the candidates; each owns one tape
     int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds + 1024, 1)));
     if (const char* env = getenv("TPHIP_GRAD_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(env));
-    const int64_t grid = std::min<int64_t>(ncand, (int64_t)p->num_cus * blocks_per_cu);
+    const int nsplit = lik_nsplit(p, ncand, kGradBlock);
+    L.nsplit = nsplit;
+    const size_t nn = (size_t)p->nnodes, items = (size_t)ncand * nsplit;
+    if (nsplit > 1) {   // partials: lnl[items], sum[items], dexch[items][6], dlogt[items][nn]
+        int rc = grow_part(p, items * (8 + (d_dlogt ? nn : 0)) * sizeof(double));
+        if (rc) return rc;
+        L.out = p->d_part;
+        G.out_sum_dlogt = p->d_part + items;
+        G.out_dexch = p->d_part + 2 * items;
+        G.out_dlogt = d_dlogt ? p->d_part + 8 * items : nullptr;
+    }
+    const int64_t grid = std::min<int64_t>((int64_t)items, (int64_t)p->num_cus * blocks_per_cu);
     const size_t need = (size_t)grid * (size_t)std::max(1, p->prog.ntape) * 4 * kGradBlock * sizeof(double);
     if (need > p->tape_bytes) {
         if (p->d_tape) { HIP_TRY(hipFree(p->d_tape)); p->d_tape = nullptr; p->tape_bytes = 0; }
@@ -565,6 +619,17 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     G.tape = p->d_tape;
     locus_grad_kernel<<<dim3((unsigned)grid), dim3(kGradBlock), lds, (hipStream_t)stream>>>(G);
     HIP_TRY(hipGetLastError());
+    if (nsplit > 1) {
+        auto sum = [&](const double* part, double* out, int width) {
+            const int64_t n = ncand * width;
+            split_sum_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(part, out, ncand, nsplit, width);
+        };
+        sum(L.out, d_lnl, 1);
+        sum(G.out_sum_dlogt, d_sum_dlogt, 1);
+        sum(G.out_dexch, d_dexch, 6);
+        if (d_dlogt) sum(G.out_dlogt, d_dlogt, (int)nn);
+        HIP_TRY(hipGetLastError());
+    }
     return TPHIP_OK;
 }
 
@@ -720,6 +785,18 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     return TPHIP_OK;
 }
 
+int tphip_plan_set_column_weights(tphip_plan* p, const double* weights) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->d_col_weight) { HIP_TRY(hipFree(p->d_col_weight)); p->d_col_weight = nullptr; }
+    if (!weights || p->ncols == 0) return TPHIP_OK;
+    for (int64_t c = 0; c < p->ncols; ++c)
+        if (!(weights[c] >= 0.0)) return fail(TPHIP_ERR_INVALID, "column weights must be >= 0");
+    HIP_TRY(hipMalloc((void**)&p->d_col_weight, sizeof(double) * (size_t)p->ncols));
+    HIP_TRY(hipMemcpy(p->d_col_weight, weights, sizeof(double) * (size_t)p->ncols, hipMemcpyHostToDevice));
+    return TPHIP_OK;
+}
+
 int tphip_free_device(tphip_plan* p, void* d_ptr) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
     HIP_TRY(hipSetDevice(p->device));
@@ -833,6 +910,80 @@ int tphip_locus_gradient(tphip_plan* p, const uint8_t* states, void** d_states_c
     HIP_TRY(hipMemcpy(dexch, d_de, sizeof(double) * n * 6, hipMemcpyDeviceToHost));
     if (dlogt) HIP_TRY(hipMemcpy(dlogt, d_dt, sizeof(double) * n * nn, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(sum_dlogt, d_st, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
+}
+
+int tphip_compress_columns(int32_t device, const uint8_t* states, int64_t ncols_total, int32_t ntaxa,
+                           const int64_t* locus_offsets, int64_t nloci, uint8_t* out_states, int64_t* out_offsets,
+                           double* out_weight, int64_t* out_map, int64_t* out_npatterns) {
+    if (tphip_device_count() <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
+    if (!states || !locus_offsets || !out_states || !out_offsets || !out_weight || !out_npatterns || nloci < 1 || ntaxa < 1 ||
+        ncols_total < 0)
+        return fail(TPHIP_ERR_INVALID, "bad arguments");
+    if (ncols_total >= ((int64_t)1 << 31)) return fail(TPHIP_ERR_INVALID, "too many columns for one call (2^31)");
+    if (nloci >= ((int64_t)1 << (64 - kPatHashBits))) return fail(TPHIP_ERR_INVALID, "too many loci for one call");
+    if (locus_offsets[0] != 0 || locus_offsets[nloci] != ncols_total) return fail(TPHIP_ERR_INVALID, "locus_offsets must span the columns");
+    for (int64_t l = 0; l < nloci; ++l)
+        if (locus_offsets[l + 1] < locus_offsets[l]) return fail(TPHIP_ERR_INVALID, "locus_offsets must not decrease");
+    if (ncols_total == 0) {
+        for (int64_t l = 0; l <= nloci; ++l) out_offsets[l] = 0;
+        *out_npatterns = 0;
+        return TPHIP_OK;
+    }
+    HIP_TRY(hipSetDevice(device));
+    Scratch S;
+    const size_t n = (size_t)ncols_total;
+    const int32_t nwords = (ntaxa + 7) / 8;
+    uint8_t* d_s = S.get<uint8_t>(n * (size_t)ntaxa);
+    int64_t* d_off = S.get<int64_t>((size_t)nloci + 1);
+    uint32_t* d_packed = S.get<uint32_t>(n * (size_t)nwords);
+    uint64_t* d_key = S.get<uint64_t>(n);
+    uint64_t* d_key2 = S.get<uint64_t>(n);
+    uint64_t* d_h2 = S.get<uint64_t>(n);
+    uint32_t* d_col = S.get<uint32_t>(n);
+    uint32_t* d_col2 = S.get<uint32_t>(n);
+    int32_t* d_head = S.get<int32_t>(n);
+    int64_t* d_incl = S.get<int64_t>(n);
+    int64_t* d_newoff = S.get<int64_t>((size_t)nloci + 1);
+    int64_t* d_map = out_map ? S.get<int64_t>(n) : nullptr;
+    if (!d_s || !d_off || !d_packed || !d_key || !d_key2 || !d_h2 || !d_col || !d_col2 || !d_head || !d_incl || !d_newoff ||
+        (out_map && !d_map))
+        return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_s, states, n * (size_t)ntaxa, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_off, locus_offsets, sizeof(int64_t) * ((size_t)nloci + 1), hipMemcpyHostToDevice));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    pack_hash_kernel<<<dim3(blocks), dim3(256)>>>(d_s, ncols_total, ntaxa, nwords, d_off, nloci, d_packed, d_key, d_h2, d_col);
+    HIP_TRY(hipGetLastError());
+    int locus_bits = 1;
+    while (((int64_t)1 << locus_bits) < nloci) ++locus_bits;
+    const int end_bit = std::min(64, kPatHashBits + locus_bits);
+    size_t tmp_sort = 0, tmp_scan = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, d_key, d_key2, d_col, d_col2, (int)n, 0, end_bit));
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, d_head, d_incl, (int)n));
+    void* d_tmp = S.get<char>(std::max(tmp_sort, tmp_scan));
+    if (!d_tmp) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_sort, d_key, d_key2, d_col, d_col2, (int)n, 0, end_bit));
+    head_flag_kernel<<<dim3(blocks), dim3(256)>>>(d_key2, d_col2, d_h2, d_packed, nwords, ncols_total, d_head);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tmp_scan, d_head, d_incl, (int)n));
+    int64_t npat = 0;
+    HIP_TRY(hipMemcpy(&npat, d_incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
+    uint8_t* d_out = S.get<uint8_t>((size_t)npat * (size_t)ntaxa);
+    int32_t* d_count = S.get<int32_t>((size_t)npat);
+    double* d_w = S.get<double>((size_t)npat);
+    if (!d_out || !d_count || !d_w) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemset(d_count, 0, sizeof(int32_t) * (size_t)npat));
+    pattern_scatter_kernel<<<dim3(blocks), dim3(256)>>>(d_col2, d_head, d_incl, d_packed, nwords, ntaxa, ncols_total, npat, d_out,
+                                                      d_count, d_map);
+    pattern_offsets_kernel<<<dim3((unsigned)((nloci + 256) / 256)), dim3(256)>>>(d_off, nloci, ncols_total, d_incl, npat, d_newoff);
+    count_to_weight_kernel<<<dim3((unsigned)((npat + 255) / 256)), dim3(256)>>>(d_count, npat, d_w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_states, d_out, (size_t)npat * (size_t)ntaxa, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_offsets, d_newoff, sizeof(int64_t) * ((size_t)nloci + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_weight, d_w, sizeof(double) * (size_t)npat, hipMemcpyDeviceToHost));
+    if (out_map) HIP_TRY(hipMemcpy(out_map, d_map, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+    *out_npatterns = npat;
     return TPHIP_OK;
 }
 

@@ -64,6 +64,8 @@ SYMBOLS = [
     ("tphip_state_histogram", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     ("tphip_eval_columns", ctypes.c_int, [_vp] * 6),
     ("tphip_locus_loglik", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 7),
+    ("tphip_plan_set_column_weights", ctypes.c_int, [_vp, _vp]),
+    ("tphip_compress_columns", ctypes.c_int, [ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     ("tphip_locus_gradient", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 10),
     ("tphip_free_device", ctypes.c_int, [_vp, _vp]),
 ]
@@ -251,6 +253,16 @@ class Plan:
                                               st.ctypes.data))
         return lnl, dex, dlt, st
 
+    def set_column_weights(self, weights):
+        """Column multiplicities for locus_loglik / locus_gradient (site-pattern counts); None removes them."""
+        if weights is None:
+            _check(self._lib.tphip_plan_set_column_weights(self._h, None))
+            return
+        w = _np(weights, np.float64).reshape(-1)
+        if w.size != self.ncols:
+            raise ValueError("weights must have one entry per column of the plan")
+        _check(self._lib.tphip_plan_set_column_weights(self._h, w.ctypes.data))
+
     def device_cache(self):
         """Holder that keeps the alignment on the device across locus_loglik calls; release() frees it."""
         return _DeviceCache(self)
@@ -309,6 +321,24 @@ def state_histogram(states, locus_offsets, device=0):
     _check(load().tphip_state_histogram(device, states.ctypes.data, ncols, ntaxa, off.ctypes.data, len(off) - 1,
                                         hist.ctypes.data))
     return hist
+
+
+def compress_columns(states, locus_offsets, device=0, want_map=True):
+    """Unique site patterns per locus (tphip_compress_columns): returns (pattern_states [ntaxa, P] uint8,
+    pattern_offsets int64[L+1], weights float64[P], column -> pattern map int64[ncols] or None)."""
+    states = _np(states, np.uint8)
+    off = _np(locus_offsets, np.int64)
+    ntaxa, ncols = states.shape
+    buf = np.empty(ntaxa * max(ncols, 1), np.uint8)
+    new_off = np.empty(len(off), np.int64)
+    w = np.empty(max(ncols, 1))
+    cmap = np.empty(max(ncols, 1), np.int64) if want_map else None
+    npat = _i64()
+    _check(load().tphip_compress_columns(device, states.ctypes.data, ncols, ntaxa, off.ctypes.data, len(off) - 1,
+                                         buf.ctypes.data, new_off.ctypes.data, w.ctypes.data,
+                                         cmap.ctypes.data if want_map else None, ctypes.byref(npat)))
+    P = npat.value
+    return buf[:ntaxa * P].reshape(ntaxa, P).copy(), new_off, w[:P].copy(), (cmap[:ncols] if want_map else None)
 
 
 def townsend_pi_dense(times, rates, device=0):

@@ -100,10 +100,13 @@ def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, bl
     """Stage 1 of models_and_rates.bf (bf:405-897) for every locus at once -> [L, 6] AC, AG(=1), AT, CG, CT, GT."""
     from . import stage1
     L = len(offsets) - 1
-    plan = eng.Plan(ntaxa, parent, blen, leaf, offsets, pi, np.ones((L, 6)), T, times, intervals,
+    # unique site patterns with counts, as HyPhy evaluates them (bf:960-963): every likelihood below runs on those
+    pstates, poffsets, weights, _ = eng.compress_columns(states, offsets, device=device, want_map=False)
+    plan = eng.Plan(ntaxa, parent, blen, leaf, poffsets, pi, np.ones((L, 6)), T, times, intervals,
                     correction=correction, device=device)
     try:
-        return stage1.model_averaged_exchangeabilities(plan, states, pi, parent, np.asarray(blen) / correction)["exch"]
+        plan.set_column_weights(weights)
+        return stage1.model_averaged_exchangeabilities(plan, pstates, pi, parent, np.asarray(blen) / correction)["exch"]
     finally:
         plan.close()
 

@@ -167,7 +167,7 @@ class _LBFGS:
 class Stage1:
     """Model-averaged exchangeabilities for every locus of a plan (see module docstring)."""
 
-    def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, verbose=False):
+    def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, analytic=None, sub_analytic=None, verbose=False):
         self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
         self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
         self.pi = self.pi / self.pi.sum(1, keepdims=True)
@@ -177,6 +177,13 @@ class Stage1:
         self.blen0 = np.asarray(blen, dtype=np.float64)
         self.h = fd_step
         self.cache = plan.device_cache()
+        # gradients: the reverse-mode kernel (tphip_locus_gradient) when the engine has it, else central differences
+        self.analytic = hasattr(plan, "locus_gradient") if analytic is None else analytic
+        # the rate-class models have <= 4 free parameters: a central-difference stencil is <= 8 value evaluations,
+        # which is what one reverse-mode gradient costs at present (measured, tools/stage1_timing.py), so they default
+        # to the stencil; the general model (5 + 2N-3 parameters) always uses the gradient kernel
+        self.sub_analytic = (analytic is True and sub_analytic is not False) if sub_analytic is None else sub_analytic
+        self.ngrads = 0
         self.verbose = verbose
         self.nevals = 0
 
@@ -202,6 +209,16 @@ class Stage1:
 
     def _grm_value_and_grad(self, X, idx):
         n, D = X.shape
+        if self.analytic:
+            vecs = np.zeros((n, self.nn))
+            vecs[:, self.branches] = np.exp(X[:, 5:])
+            exch = self._exch_from_free(X[:, :5])
+            self.ngrads += n
+            lnl, dex, dlt, _ = self.plan.locus_gradient(self.states, vecs, idx, exch, cache=self.cache)
+            g = np.empty((n, D))
+            g[:, :5] = dex[:, [0, 2, 3, 4, 5]] * exch[:, [0, 2, 3, 4, 5]]     # d/d log r = r d/dr
+            g[:, 5:] = dlt[:, self.branches]
+            return -lnl, -g
         nb = len(self.branches)
         h = self.h
         vecs = np.zeros((n, self.nn))
@@ -273,6 +290,20 @@ class Stage1:
 
     def _sub_value_and_grad(self, X, idx):
         n, D = X.shape
+        if self.sub_analytic:
+            cls = self._sub_cls[idx]
+            exch, loc, scale = self._sub_eval(X, idx, cls)
+            self.ngrads += n
+            lnl, dex, _, sdl = self.plan.locus_gradient(self.states, self._stash, loc, exch, loc, scale, cache=self.cache,
+                                                        per_branch=False)
+            # t_b = stash_b / totalFactor(r): d log t_b / d r_q = -(2 pi_i pi_j) / totalFactor for every branch
+            pi = self.pi[loc]
+            dk = np.stack([2.0 * pi[:, i] * pi[:, j] for i, j in _PAIRS], axis=1)
+            dr = (dex - sdl[:, None] * dk * scale[:, None]) * exch              # d lnL / d log r_q, q over the six rates
+            g = np.zeros((n, D))
+            for c in range(D):
+                g[:, c] = (dr * (cls == c)).sum(1)
+            return -lnl, -np.where(self._sub_active[idx], g, 0.0)
         h = self.h
         per = 1 + 2 * D
         Xr = np.repeat(X[:, None, :], per, axis=1)
@@ -327,7 +358,7 @@ class Stage1:
         avg = (w[:, :, None] * exch).sum(axis=1)
         avg[:, 1] = 1.0
         return dict(exch=avg, weights=w, lnl=lnl, model_exch=exch, grm_exch=grm_exch, grm_blen=grm_t,
-                    models=model_strings(), nevals=self.nevals)
+                    models=model_strings(), nevals=self.nevals, ngrads=self.ngrads)
 
 
 def model_averaged_exchangeabilities(plan, states, pi, parent, blen, **kw):

@@ -21,6 +21,13 @@ def state_histogram(states, locus_offsets, device=0):
     return hist
 
 
+def compress_columns(states, locus_offsets, device=0, want_map=True):
+    """Stand-in: no compression (every column its own pattern, weight 1)."""
+    states = np.asarray(states, np.uint8)
+    n = states.shape[1]
+    return states, np.asarray(locus_offsets, np.int64), np.ones(n), (np.arange(n) if want_map else None)
+
+
 class Plan:
     def __init__(self, ntaxa, parent, branch_len, leaf_taxon, locus_offsets, pi, exch, T, times, intervals,
                  correction=1.0, threshold=3, round_decimals=4, integ_mode=0, device=0):
@@ -51,6 +58,9 @@ class Plan:
 
     def device_cache(self):
         return Plan._Cache()
+
+    def set_column_weights(self, weights):
+        assert weights is None or np.all(np.asarray(weights) == 1.0)
 
     def locus_loglik(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
                      cand_pfac=None, cache=None):

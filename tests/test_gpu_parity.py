@@ -517,3 +517,64 @@ def test_locus_gradient_vs_oracle_finite_differences(oracle):
         tol = 2e-6 * max(1.0, np.abs(rdex).max(), np.abs(rdlt).max())
         assert np.max(np.abs(dex[0] - rdex)) < tol and np.max(np.abs(dlt[0] - rdlt)) < tol
         plan.close()
+
+
+def test_compress_columns_exact_and_weighted_likelihood(oracle):
+    """Site-pattern compression (HyPhy's dupInfo, bf:960-963): the patterns of every locus are exactly its set of
+    distinct columns (after 0 -> 15 normalisation), counts add up, the map points every column at an identical
+    pattern, loci never mix (identical columns in different loci stay separate), empty loci survive; and the
+    weighted likelihood / gradient on the patterns equals the plain one on all columns."""
+    engine = _engine()
+    from tapir_amd import synth
+    rng = np.random.default_rng(3)
+    ntaxa = 11
+    d = synth.simulate(4, 500, ntaxa, 77, rate_mean=0.002)   # slow: plenty of duplicate columns
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy().copy()
+    st[3, 7] = 0                             # 0 is read as 15 (all states)
+    st[:, 1000:1500] = st[:, 0:500]          # locus 3 repeats locus 0 column by column
+    off = np.array([0, 500, 500, 1000, 1500, 2000])   # an empty locus in the middle
+    pst, poff, w, cmap = engine.compress_columns(st, off)
+    assert pst.shape[0] == ntaxa and poff[0] == 0 and poff[-1] == pst.shape[1] == len(w)
+    assert w.sum() == 2000 and np.all(w >= 1)
+    norm = np.where(st == 0, 15, st & 15)
+    for l in range(5):
+        cols = norm[:, off[l]:off[l + 1]]
+        pats = pst[:, poff[l]:poff[l + 1]]
+        uniq, counts = np.unique(cols, axis=1, return_counts=True)
+        assert pats.shape[1] == uniq.shape[1]
+        order = np.lexsort(pats[::-1])                      # np.unique sorts columns lexicographically
+        assert np.array_equal(pats[:, order], uniq)
+        assert np.array_equal(w[poff[l]:poff[l + 1]][order], counts)
+        assert np.all((cmap[off[l]:off[l + 1]] >= poff[l]) & (cmap[off[l]:off[l + 1]] < poff[l + 1]))
+    assert np.array_equal(pst[:, cmap], norm)
+    assert poff[1] == poff[2] and (poff[1] - poff[0]) == (poff[4] - poff[3])
+    # deterministic
+    pst2, poff2, w2, cmap2 = engine.compress_columns(st, off)
+    assert np.array_equal(pst, pst2) and np.array_equal(w, w2) and np.array_equal(cmap, cmap2)
+    assert pst.shape[1] < 1200
+    # weighted likelihood and gradient on patterns == unweighted on columns
+    pi = np.vstack([d["pi"][0], d["pi"][1], d["pi"][1], d["pi"][2], d["pi"][3]])
+    ex = np.ones((5, 6))
+    full = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, pi, ex, 3, [1], [[0, 1]])
+    comp = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], poff, pi, ex, 3, [1], [[0, 1]])
+    comp.set_column_weights(w)
+    cl = np.array([0, 1, 2, 3, 4, 2])
+    ce = np.exp(rng.normal(0, 0.4, (6, 6)))
+    cb = np.asarray(pin["blen"])[None, :] * np.exp(rng.normal(0, 0.5, (6, len(pin["parent"])))) * 0.01
+    a = full.locus_gradient(st, cb, cl, ce)
+    b = comp.locus_gradient(pst, cb, cl, ce)
+    assert a[0][1] == 0.0 and b[0][1] == 0.0   # the empty locus
+    for x, y in zip(a, b):
+        assert np.max(np.abs(x - y)) <= 1e-10 * max(1.0, np.abs(x).max())
+    va, vb = full.locus_loglik(st, cb, cl, ce), comp.locus_loglik(pst, cb, cl, ce)
+    assert np.max(np.abs(va - vb)) <= 1e-11 * np.abs(va).max()
+    comp.set_column_weights(None)
+    assert abs(comp.locus_loglik(pst, cb, cl, ce)[0] - vb[0]) > 1.0   # weights really were in use
+    full.close()
+    comp.close()
+    # all-gap alignment, single column, a locus of identical columns
+    one = engine.compress_columns(np.full((3, 1), 15, np.uint8), [0, 1])
+    assert one[0].shape == (3, 1) and one[2][0] == 1
+    same = engine.compress_columns(np.tile(np.array([[1], [2], [4]], np.uint8), (1, 1000)), [0, 400, 1000])
+    assert same[0].shape == (3, 2) and list(same[2]) == [400, 600] and list(same[1]) == [0, 1, 2]

@@ -1,5 +1,5 @@
 """Wall time of stage 1 (model-averaged exchangeabilities) on the GPU for a synthetic batch.
-usage: python tools/stage1_timing.py LOCI COLS TAXA"""
+usage: python tools/stage1_timing.py LOCI COLS TAXA [analytic|fd]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,11 +12,13 @@ st = d["states"].numpy()
 pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, d["locus_offsets"]))
 plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"], [1], [[0, 1]],
                    correction=pin["correction"])
-s1 = stage1.Stage1(plan, st, pi, pin["parent"], np.asarray(pin["blen"]) / pin["correction"])
+analytic = None if len(sys.argv) < 5 else (sys.argv[4] == "analytic")
+s1 = stage1.Stage1(plan, st, pi, pin["parent"], np.asarray(pin["blen"]) / pin["correction"], analytic=analytic)
 t0 = time.time(); ge, gt, gl = s1.fit_grm(); t1 = time.time()
-e1 = s1.nevals
+e1, g1 = s1.nevals, s1.ngrads
 sub = s1.fit_submodels(ge, gt); t2 = time.time()
 print("loci %d cols %d taxa %d" % (L, n, nt))
+print("gradients: general model %d, rate-class models %d" % (g1, s1.ngrads - g1))
 print("general model: %.2f s, %d likelihood evaluations, iterations max %d mean %.1f" % (t1 - t0, e1, s1.grm_iters.max(), s1.grm_iters.mean()))
 print("202 models   : %.2f s, %d likelihood evaluations, iterations max %d mean %.1f" % (t2 - t1, s1.nevals - e1, s1.sub_iters.max(), s1.sub_iters.mean()))
 print("column-evaluations/s: %.3e" % (s1.nevals * n / (t2 - t0)))
