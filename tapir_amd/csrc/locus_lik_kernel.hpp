@@ -7,10 +7,10 @@
 // rate-class models), which is what makes the problem GPU-shaped: one workgroup per (locus, candidate).
 //
 //   1. thread 0 builds Q = R o pi for the candidate's exchangeabilities and diagonalises it (4x4 Jacobi);
-//   2. all threads fill an LDS table of transition matrices P_b = U exp(Lambda t_b) U^-1, one per tree branch;
-//   3. threads stride over the locus' columns and prune with the same uniform op stream as site_rate_kernel,
-//      value only: a tip contributes sum_{x in mask} P_b[.][x], an internal branch one 4x4 mat-vec; parked
-//      siblings go to an LDS stack [slot][state][thread];
+//   2. all threads fill an LDS table exp(Lambda t_b), 4 doubles per tree branch;
+//   3. threads stride over the slice's columns and prune with the same uniform op stream as site_rate_kernel,
+//      value only, in the eigenbasis (see locus_loglik_kernel); parked siblings go to an LDS stack
+//      [slot][state][thread];
 //   4. log L summed over the columns by a fixed-order block reduction.
 //
 // Bound: FP64 VALU for short loci (the per-candidate eigen-system and ~130 matrix exponentials), the L2-resident
@@ -23,7 +23,7 @@
 
 namespace tphip {
 
-constexpr int kLikBlock = 256;
+constexpr int kLikBlock = 128;
 
 struct LikParams {
     const uint8_t* states;         // [ntaxa][ncols_total]
@@ -31,9 +31,12 @@ struct LikParams {
     const int64_t* locus_offsets;  // [nloci+1]
     const double* col_weight;      // [ncols_total] multiplicity of each column (site-pattern counts), null = 1
     const LocusModel* models;      // [nloci] (only pi is used)
-    const TreeOp* ops;             // shared traversal program
-    const int32_t* op_node;        // [nops] node whose branch the op climbs
+    const int4* lops;              // [nops] traversal program for these kernels: {code, taxon, node whose branch the op
+                                   // climbs, tape slot (BRANCH / PUSH: written; POP_MUL: the PUSH it pops)} -- one 16-byte
+                                   // scalar load per op, fetched one op ahead
     int32_t nops;
+    int32_t ntaxa;
+    int32_t stage_states;          // 1: the block's state masks are staged in LDS [ntaxa][block] before each sweep
     int32_t nnodes;
     int32_t stack_depth;
     const int32_t* cand_locus;     // [ncand]
@@ -108,11 +111,40 @@ __device__ inline void lik_eigen(const double* pi, const double* e, double* eig)
     }
 }
 
+// wave-uniform double -> scalar registers
+__device__ inline double lik_uniform(double v) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// State masks of the block's columns: either staged in LDS (all loads of a column block in flight at once, then
+// LDS-latency reads in the sweeps) or, for trees too large for that, read from global memory op by op.
+__device__ inline void lik_stage_states(const LikParams& P, uint8_t* sts, int64_t c, int block) {
+    for (int t = 0; t < P.ntaxa; ++t) {
+        unsigned m = P.states[(int64_t)t * P.ncols_total + c] & 15u;
+        sts[t * block + threadIdx.x] = (uint8_t)(m ? m : 15u);
+    }
+}
+__device__ inline unsigned lik_tip_mask(const LikParams& P, const uint8_t* sts, int taxon, int64_t c, int block) {
+    if (P.stage_states) return sts[taxon * block + threadIdx.x];
+    const unsigned m = P.states[(int64_t)taxon * P.ncols_total + c] & 15u;
+    return m ? m : 15u;
+}
+
+// locus_loglik_kernel: value only.  Works in the eigenbasis of Q = U Lambda U^-1 (reversible, so U^-1 = U^T diag(pi)):
+//   tip    acc *= U (e_b o Y[mask])            Y[mask] = U^-1 (0/1 vector of the tip's state mask), 16-entry LDS table
+//   branch acc  = U (e_b o U^T (pi o acc))     e_b = exp(Lambda t_b), 4 doubles per branch in LDS
+// U, pi are wave-uniform and live in scalar registers; a tip costs 8 LDS reads and 24 FP64 instructions, no
+// per-state select chains (the first version kept 4x4 transition matrices in LDS and was LDS-bandwidth bound).
 __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
     extern __shared__ double lds[];
-    double* Pm = lds;                                   // [nnodes][16]
-    double* stack = Pm + (size_t)P.nnodes * 16;         // [depth][4][kLikBlock]
+    double* ET = lds;                                   // [nnodes][4] exp(lam_k t_b)
+    double* stack = ET + (size_t)P.nnodes * 4;          // [depth][4][kLikBlock]
+    uint8_t* sts = (uint8_t*)(stack + (size_t)P.stack_depth * 4 * kLikBlock);   // [ntaxa][kLikBlock] when staged
     __shared__ double eig[4 + 16 + 16];                 // lam[4], U[16], Ui[16]
+    __shared__ double tipY[16 * 4];
     __shared__ double red[kLikBlock / 64];
     const int64_t cand = blockIdx.x / P.nsplit;
     const int locus = P.cand_locus[cand];
@@ -122,22 +154,30 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
         if (threadIdx.x == 0) P.out[blockIdx.x] = 0.0;
         return;
     }
-    const double* pi = P.models[locus].pi;
-    if (threadIdx.x == 0) lik_eigen(pi, P.cand_exch + (size_t)cand * 6, eig);
+    const double* pig = P.models[locus].pi;
+    if (threadIdx.x == 0) lik_eigen(pig, P.cand_exch + (size_t)cand * 6, eig);
     __syncthreads();
-    // transition matrices: P_b[i][j] = sum_k U[i][k] exp(lam_k t_b) Ui[k][j]
     const double* bl = P.blen_vecs + (size_t)P.cand_vec[cand] * P.nnodes;
     const double bscale = P.cand_scale[cand], pfac = P.cand_pfac[cand];
     const int pidx = P.cand_pidx[cand];
-    for (int idx = threadIdx.x; idx < P.nnodes * 16; idx += kLikBlock) {
-        const int b = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
+    for (int idx = threadIdx.x; idx < P.nnodes * 4; idx += kLikBlock) {
+        const int b = idx >> 2, k = idx & 3;
         const double t = bl[b] * bscale * (b == pidx ? pfac : 1.0);
+        ET[idx] = exp(eig[k] * t);
+    }
+    if (threadIdx.x < 64) {
+        const int m = threadIdx.x >> 2, k = threadIdx.x & 3;
         double s = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s = fma(eig[4 + i * 4 + k] * exp(eig[k] * t), eig[20 + k * 4 + j], s);
-        Pm[idx] = s;
+        for (int j = 0; j < 4; ++j) s += ((m >> j) & 1) ? eig[20 + k * 4 + j] : 0.0;
+        tipY[threadIdx.x] = s;
     }
     __syncthreads();
+    double U[16], pi[4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) U[i] = lik_uniform(eig[4 + i]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pi[k] = lik_uniform(pig[k]);
     double total = 0.0;
     for (int64_t base = lo; base < hi; base += kLikBlock) {   // uniform trip count: every thread meets the LDS stack
         const int64_t col = base + threadIdx.x;
@@ -145,20 +185,21 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
         const int64_t c = active ? col : lo;
         double acc[4] = {1.0, 1.0, 1.0, 1.0};
         int scale = 0, sp = 0;
+        if (P.stage_states) lik_stage_states(P, sts, c, kLikBlock);
+        int4 nxt = P.lops[0];
         for (int ip = 0; ip < P.nops; ++ip) {
-            const TreeOp op = P.ops[ip];
-            if (op.code <= OP_TIP_MUL) {
-                unsigned m = P.states[(int64_t)op.taxon * P.ncols_total + c] & 15u;
-                m = m ? m : 15u;
-                const double* Pb = Pm + (size_t)P.op_node[ip] * 16;
+            const int4 op = nxt;
+            if (ip + 1 < P.nops) nxt = P.lops[ip + 1];
+            if (op.x <= OP_TIP_MUL) {
+                const unsigned m = lik_tip_mask(P, sts, op.y, c, kLikBlock);
+                const double* et = ET + (size_t)op.z * 4;
+                double z[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    double v = 0;
+                for (int k = 0; k < 4; ++k) z[k] = et[k] * tipY[m * 4 + k];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v += ((m >> j) & 1u) ? Pb[i * 4 + j] : 0.0;
-                    acc[i] *= v;
-                }
-            } else if (op.code == OP_BRANCH) {
+                for (int i = 0; i < 4; ++i)
+                    acc[i] *= fma(U[i * 4 + 3], z[3], fma(U[i * 4 + 2], z[2], fma(U[i * 4 + 1], z[1], U[i * 4] * z[0])));
+            } else if (op.x == OP_BRANCH) {
                 const double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
                 if (mx < 1e-200 && mx > 0) {   // rescale (deep trees); rare, lane-divergent is fine here
                     int e;
@@ -166,14 +207,17 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
                     for (int i = 0; i < 4; ++i) acc[i] = ldexp(acc[i], -e);
                     scale += e;
                 }
-                const double* Pb = Pm + (size_t)P.op_node[ip] * 16;
-                double r[4];
+                const double* et = ET + (size_t)op.z * 4;
+                double w[4], y[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = pi[i] * acc[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    y[k] = et[k] * fma(U[12 + k], w[3], fma(U[8 + k], w[2], fma(U[4 + k], w[1], U[k] * w[0])));
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    r[i] = fma(Pb[i * 4 + 3], acc[3], fma(Pb[i * 4 + 2], acc[2], fma(Pb[i * 4 + 1], acc[1], Pb[i * 4] * acc[0])));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = r[i];
-            } else if (op.code == OP_PUSH) {
+                    acc[i] = fma(U[i * 4 + 3], y[3], fma(U[i * 4 + 2], y[2], fma(U[i * 4 + 1], y[1], U[i * 4] * y[0])));
+            } else if (op.x == OP_PUSH) {
                 double* slot = stack + ((size_t)sp * 4) * kLikBlock + threadIdx.x;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { slot[i * kLikBlock] = acc[i]; acc[i] = 1.0; }
@@ -196,7 +240,11 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
     for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = total;
     __syncthreads();
-    if (threadIdx.x == 0) P.out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int w = 0; w < kLikBlock / 64; ++w) s += red[w];
+        P.out[blockIdx.x] = s;
+    }
 }
 
 // ---- value + gradient --------------------------------------------------------------------------------------
@@ -205,30 +253,41 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
 // exchangeabilities from one forward + one reverse sweep over the op stream (reverse-mode differentiation of the
 // pruning recursion), instead of 2 x (5 + 2N-3) extra likelihood evaluations for a finite-difference stencil.
 //
-//   forward : as locus_loglik_kernel, and the partial entering every BRANCH and every PUSHed partial go to a tape
-//             in global memory, [slot][state][thread] (coalesced; ~1.5 (N-2) slots of 32 B per column);
+// Everything is done in the eigenbasis of Q = U Lambda U^-1.  Q is reversible, so U^-1 = U^T diag(pi) and the
+// three mat-vecs of a branch need U only (16 doubles, wave-uniform -> scalar registers) plus pi:
+//       y = U^-1 a = U^T (pi o a),     message = U (e^{Lambda t} o y),     U^-T z = pi o (U z).
+//
+//   forward : tips  acc *= U (e_b o Y[mask])         (Y[mask] = U^-1 of the tip's 0/1 state vector, 16-entry LDS table)
+//             inner acc  = U (e_b o U^T (pi o acc)); the partial entering every BRANCH and every PUSHed partial go
+//             to a tape in global memory, [slot][state][thread] (coalesced; ~1.5 (N-2) slots of 32 B per column);
 //   reverse : carries abar = d log L / d acc back through the ops.  For a branch b with incoming partial a and
-//             outgoing adjoint abar, with x = U^T abar and y = U^-1 a in the eigenbasis of Q:
+//             outgoing adjoint abar, with x = U^T abar and y = U^-1 a:
 //                 d log L / d t_b          = sum_k x_k lam_k e^{lam_k t_b} y_k
 //                 d log L / d theta (in Q) = sum_kl x_k F_kl(t_b) y_l G_kl,   G = U^-1 (dQ/dtheta) U,
 //                 F_kl = (e^{lam_k t} - e^{lam_l t}) / (lam_k - lam_l),  F_kk = t e^{lam_k t}   (Daleckii-Krein)
 //             so the exchangeability derivatives of ALL branches and columns collapse into one 4x4 matrix
 //             W_kl = sum x_k F_kl y_l per candidate, contracted with G for the six rates at the very end.
-//             Tip branches are the same with a = the tip's 0/1 state vector (y from a 16-entry table by state mask)
-//             and abar = the adjoint of the tip's message; the running partial is un-multiplied (acc / message).
+//             Tip branches are the same with y = Y[mask] and abar = the adjoint of the tip's message; the running
+//             partial is un-multiplied (acc * 1/message).  Per-branch sums over the lanes go through LDS atomics
+//             spread over kGradSlots addresses per (wave, branch).
 //   outputs : lnL, d lnL / d r (6), d lnL / d log t_b (per branch, optional) and its sum over branches (what a
 //             rate-class model needs, whose branch lengths are one stashed vector times 1/totalFactor(rates)).
+//
+// Bound: FP64 VALU (~150 flop-instructions per branch per column); the tape adds 64 B of HBM/L2 traffic per
+// branch per column.  LDS holds only the per-branch tables (11 doubles) and the branch accumulators.
+#ifndef TPHIP_GRAD_MIN_WAVES
+#define TPHIP_GRAD_MIN_WAVES 2   // waves per SIMD the register allocation must allow (2: <= 256 VGPRs, no scratch)
+#endif
 constexpr int kGradBlock = 128;
 constexpr int kGradWaves = kGradBlock / 64;
-constexpr int kGradEF = 12;  // per node: e^{lam_k t}[4], F01 F02 F03 F12 F13 F23, t, pad
+constexpr int kGradEF = 12;     // per node: e^{lam_k t}[4], F01 F02 F03 F12 F13 F23, t, pad
+constexpr int kGradSlots = 4;   // LDS accumulator addresses per (wave, branch)
 
 struct GradParams {
     LikParams L;                // candidates as for locus_loglik_kernel (cand_pidx / cand_pfac are honoured too); L.out = lnL
-    const int32_t* op_tape;     // [nops] tape slot written by a BRANCH / PUSH op, -1 otherwise
-    const int32_t* op_partner;  // [nops] for POP_MUL: tape slot of the PUSH it pops
-    int32_t ntape;
+    int32_t ntape;              // slots written by the forward sweep; the reverse sweep's adjoint stack follows them
     int64_t ncand;
-    double* tape;               // [gridDim.x][ntape][4][kGradBlock]
+    double* tape;               // [gridDim.x][ntape + stack_depth][4][kGradBlock]
     // outputs are indexed by work item = cand * nsplit + slice (partials when nsplit > 1)
     double* out_dexch;          // [items][6]   d lnL / d r  (AC, AG, AT, CG, CT, GT), branch lengths held fixed
     double* out_dlogt;          // [items][nnodes] d lnL / d log t_b, or null
@@ -241,19 +300,27 @@ __device__ inline double lik_wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
+__device__ inline double lik_rcp(double v) {   // 1/v to < 1 ulp-ish: hardware estimate + two Newton steps
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
+__global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_kernel(GradParams G) {
     const LikParams& P = G.L;
     extern __shared__ double lds[];
     const int nn = P.nnodes;
-    double* Pm = lds;                                   // [nn][16]
-    double* EF = Pm + (size_t)nn * 16;                  // [nn][kGradEF]
-    double* gb = EF + (size_t)nn * kGradEF;             // [kGradWaves][nn]
-    double* stack = gb + (size_t)kGradWaves * nn;       // [depth][4][kGradBlock]
+    double* EF = lds;                                   // [nn][kGradEF]
+    double* gb = EF + (size_t)nn * kGradEF;             // [kGradWaves][nn][kGradSlots]
+    uint8_t* sts = (uint8_t*)(gb + (size_t)kGradWaves * nn * kGradSlots);   // [ntaxa][kGradBlock] when staged
     __shared__ double eig[36];
     __shared__ double tipY[16 * 4];
     __shared__ double red[kGradWaves * 18];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double* tape = G.tape + (size_t)blockIdx.x * (size_t)G.ntape * 4 * kGradBlock + tid;
+    double* tape = G.tape + (size_t)blockIdx.x * (size_t)(G.ntape + P.stack_depth) * 4 * kGradBlock + tid;
+    double* astack = tape + (size_t)G.ntape * 4 * kGradBlock;
+    double* gbw = gb + ((size_t)wave * nn) * kGradSlots + (lane & (kGradSlots - 1));
     const int64_t nitems = G.ncand * P.nsplit;
     for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         __syncthreads();
@@ -267,20 +334,12 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
             if (G.out_dlogt) for (int b = tid; b < nn; b += kGradBlock) G.out_dlogt[item * nn + b] = 0.0;
             continue;
         }
-        const double* pi = P.models[locus].pi;
-        if (tid == 0) lik_eigen(pi, P.cand_exch + (size_t)cand * 6, eig);
+        const double* pig = P.models[locus].pi;
+        if (tid == 0) lik_eigen(pig, P.cand_exch + (size_t)cand * 6, eig);
         __syncthreads();
         const double* bl = P.blen_vecs + (size_t)P.cand_vec[cand] * nn;
         const double bscale = P.cand_scale[cand], pfac = P.cand_pfac[cand];
         const int pidx = P.cand_pidx[cand];
-        for (int idx = tid; idx < nn * 16; idx += kGradBlock) {
-            const int b = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;
-            const double t = bl[b] * bscale * (b == pidx ? pfac : 1.0);
-            double s = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) s = fma(eig[4 + i * 4 + k] * exp(eig[k] * t), eig[20 + k * 4 + j], s);
-            Pm[idx] = s;
-        }
         for (int b = tid; b < nn; b += kGradBlock) {
             const double t = bl[b] * bscale * (b == pidx ? pfac : 1.0);
             double e[4];
@@ -297,9 +356,9 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
                 }
             EF[b * kGradEF + 10] = t;
             EF[b * kGradEF + 11] = 0.0;
-            for (int w = 0; w < kGradWaves; ++w) gb[w * nn + b] = 0.0;
+            for (int w = 0; w < kGradWaves * kGradSlots; ++w) gb[((size_t)(w / kGradSlots) * nn + b) * kGradSlots + (w % kGradSlots)] = 0.0;
         }
-        if (tid < 64) {  // y of a tip = U^-1 (0/1 vector of the state mask)
+        if (tid < 64) {  // Y[mask] = U^-1 (0/1 vector of the state mask)
             const int m = tid >> 2, k = tid & 3;
             double s = 0;
 #pragma unroll
@@ -307,35 +366,40 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
             tipY[tid] = s;
         }
         __syncthreads();
-        double U[16], Ui[16], lam[4];
+        double U[16], lam[4], pi[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { U[i] = eig[4 + i]; Ui[i] = eig[20 + i]; }
+        for (int i = 0; i < 16; ++i) U[i] = lik_uniform(eig[4 + i]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lam[k] = eig[k];
+        for (int k = 0; k < 4; ++k) { lam[k] = lik_uniform(eig[k]); pi[k] = lik_uniform(pig[k]); }
         double total = 0.0;
         double W[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) W[i] = 0.0;
 
-        // x = U^T abar, y given: accumulate W and the branch-length derivative of `node`
-        auto contribute = [&](int node, const double* x, const double* y) {
-            const double* ef = EF + (size_t)node * kGradEF;
+        // r = U z   and   r = U^T z
+        auto mulU = [&](const double* z, double* r) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = fma(U[i * 4 + 3], z[3], fma(U[i * 4 + 2], z[2], fma(U[i * 4 + 1], z[1], U[i * 4] * z[0])));
+        };
+        auto mulUt = [&](const double* z, double* r) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = fma(U[12 + k], z[3], fma(U[8 + k], z[2], fma(U[4 + k], z[1], U[k] * z[0])));
+        };
+        // x = U^T abar, y = U^-1 a: accumulate W and the branch-length derivative of `node`
+        auto contribute = [&](const double* ef, int node, const double* x, const double* y) {
             const double e0 = ef[0], e1 = ef[1], e2 = ef[2], e3 = ef[3], t = ef[10];
             const double f01 = ef[4], f02 = ef[5], f03 = ef[6], f12 = ef[7], f13 = ef[8], f23 = ef[9];
-            W[0] = fma(x[0] * (t * e0), y[0], W[0]);  W[1] = fma(x[0] * f01, y[1], W[1]);
+            const double d0 = x[0] * y[0] * e0, d1 = x[1] * y[1] * e1, d2 = x[2] * y[2] * e2, d3 = x[3] * y[3] * e3;
+            W[0] = fma(t, d0, W[0]);                  W[1] = fma(x[0] * f01, y[1], W[1]);
             W[2] = fma(x[0] * f02, y[2], W[2]);       W[3] = fma(x[0] * f03, y[3], W[3]);
-            W[4] = fma(x[1] * f01, y[0], W[4]);       W[5] = fma(x[1] * (t * e1), y[1], W[5]);
+            W[4] = fma(x[1] * f01, y[0], W[4]);       W[5] = fma(t, d1, W[5]);
             W[6] = fma(x[1] * f12, y[2], W[6]);       W[7] = fma(x[1] * f13, y[3], W[7]);
             W[8] = fma(x[2] * f02, y[0], W[8]);       W[9] = fma(x[2] * f12, y[1], W[9]);
-            W[10] = fma(x[2] * (t * e2), y[2], W[10]); W[11] = fma(x[2] * f23, y[3], W[11]);
+            W[10] = fma(t, d2, W[10]);                W[11] = fma(x[2] * f23, y[3], W[11]);
             W[12] = fma(x[3] * f03, y[0], W[12]);     W[13] = fma(x[3] * f13, y[1], W[13]);
-            W[14] = fma(x[3] * f23, y[2], W[14]);     W[15] = fma(x[3] * (t * e3), y[3], W[15]);
-            double c = x[0] * (lam[0] * e0) * y[0];
-            c = fma(x[1] * (lam[1] * e1), y[1], c);
-            c = fma(x[2] * (lam[2] * e2), y[2], c);
-            c = fma(x[3] * (lam[3] * e3), y[3], c);
-            c = lik_wave_sum(c);
-            if (lane == 0) gb[wave * nn + node] += c;
+            W[14] = fma(x[3] * f23, y[2], W[14]);     W[15] = fma(t, d3, W[15]);
+            const double c = fma(lam[3], d3, fma(lam[2], d2, fma(lam[1], d1, lam[0] * d0)));
+            atomicAdd(gbw + (size_t)node * kGradSlots, c);
         };
 
         for (int64_t base = lo; base < hi; base += kGradBlock) {
@@ -343,23 +407,24 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
             const bool active = col < hi;
             const int64_t c = active ? col : lo;
             double acc[4] = {1.0, 1.0, 1.0, 1.0};
-            int scale = 0, sp = 0;
+            int scale = 0;
+            if (P.stage_states) lik_stage_states(P, sts, c, kGradBlock);
             // ---------------- forward ----------------
+            int4 nxt = P.lops[0];
             for (int ip = 0; ip < P.nops; ++ip) {
-                const TreeOp op = P.ops[ip];
-                if (op.code <= OP_TIP_MUL) {
-                    unsigned m = P.states[(int64_t)op.taxon * P.ncols_total + c] & 15u;
-                    m = m ? m : 15u;
-                    const double* Pb = Pm + (size_t)P.op_node[ip] * 16;
+                const int4 op = nxt;
+                if (ip + 1 < P.nops) nxt = P.lops[ip + 1];
+                if (op.x <= OP_TIP_MUL) {
+                    const unsigned m = lik_tip_mask(P, sts, op.y, c, kGradBlock);
+                    const double* ef = EF + (size_t)op.z * kGradEF;
+                    double z[4], v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        double v = 0;
+                    for (int k = 0; k < 4; ++k) z[k] = ef[k] * tipY[m * 4 + k];
+                    mulU(z, v);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v += ((m >> j) & 1u) ? Pb[i * 4 + j] : 0.0;
-                        acc[i] *= v;
-                    }
-                } else if (op.code == OP_BRANCH) {
-                    double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+                    for (int i = 0; i < 4; ++i) acc[i] *= v[i];
+                } else if (op.x == OP_BRANCH) {
+                    double* slot = tape + (size_t)op.w * 4 * kGradBlock;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) slot[i * kGradBlock] = acc[i];   // raw: the reverse sweep redoes the rescale
                     const double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
@@ -369,21 +434,20 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
                         for (int i = 0; i < 4; ++i) acc[i] = ldexp(acc[i], -e);
                         scale += e;
                     }
-                    const double* Pb = Pm + (size_t)P.op_node[ip] * 16;
-                    double r[4];
+                    const double* ef = EF + (size_t)op.z * kGradEF;
+                    double w[4], y[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        r[i] = fma(Pb[i * 4 + 3], acc[3], fma(Pb[i * 4 + 2], acc[2], fma(Pb[i * 4 + 1], acc[1], Pb[i * 4] * acc[0])));
+                    for (int i = 0; i < 4; ++i) w[i] = pi[i] * acc[i];
+                    mulUt(w, y);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = r[i];
-                } else if (op.code == OP_PUSH) {
-                    double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+                    for (int k = 0; k < 4; ++k) y[k] *= ef[k];
+                    mulU(y, acc);
+                } else if (op.x == OP_PUSH) {
+                    double* slot = tape + (size_t)op.w * 4 * kGradBlock;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { slot[i * kGradBlock] = acc[i]; acc[i] = 1.0; }
-                    ++sp;   // the value itself lives on the tape; `stack` is only the reverse sweep's adjoint stack
                 } else {
-                    --sp;
-                    const double* slot = tape + (size_t)G.op_partner[ip] * 4 * kGradBlock;
+                    const double* slot = tape + (size_t)op.w * 4 * kGradBlock;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] *= slot[i * kGradBlock];
                 }
@@ -395,33 +459,29 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
             const double seed = cw / Lc;   // padding lanes contribute exact zeros
             double ab[4] = {pi[0] * seed, pi[1] * seed, pi[2] * seed, pi[3] * seed};
             int asp = 0;
+            nxt = P.lops[P.nops - 1];
             for (int ip = P.nops - 1; ip >= 0; --ip) {
-                const TreeOp op = P.ops[ip];
-                if (op.code <= OP_TIP_MUL) {
-                    unsigned m = P.states[(int64_t)op.taxon * P.ncols_total + c] & 15u;
-                    m = m ? m : 15u;
-                    const int node = P.op_node[ip];
-                    const double* Pb = Pm + (size_t)node * 16;
-                    double vb[4];
+                const int4 op = nxt;
+                if (ip > 0) nxt = P.lops[ip - 1];
+                if (op.x <= OP_TIP_MUL) {
+                    const unsigned m = lik_tip_mask(P, sts, op.y, c, kGradBlock);
+                    const int node = op.z;
+                    const double* ef = EF + (size_t)node * kGradEF;
+                    double y[4], z[4], v[4], vb[4], x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { y[k] = tipY[m * 4 + k]; z[k] = ef[k] * y[k]; }
+                    mulU(z, v);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        double v = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v += ((m >> j) & 1u) ? Pb[i * 4 + j] : 0.0;
-                        acc[i] = acc[i] / v;        // the partial before this tip was folded in
+                        acc[i] *= lik_rcp(v[i]);    // the partial before this tip was folded in
                         vb[i] = ab[i] * acc[i];     // adjoint of the tip's message
-                        ab[i] *= v;
+                        ab[i] *= v[i];
                     }
-                    double x[4], y[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        x[k] = fma(U[12 + k], vb[3], fma(U[8 + k], vb[2], fma(U[4 + k], vb[1], U[k] * vb[0])));
-                        y[k] = tipY[m * 4 + k];
-                    }
-                    contribute(node, x, y);
-                } else if (op.code == OP_BRANCH) {
-                    const int node = P.op_node[ip];
-                    const double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+                    mulUt(vb, x);
+                    contribute(ef, node, x, y);
+                } else if (op.x == OP_BRANCH) {
+                    const int node = op.z;
+                    const double* slot = tape + (size_t)op.w * 4 * kGradBlock;
                     double a[4], as[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { a[i] = slot[i * kGradBlock]; as[i] = a[i]; }
@@ -433,33 +493,34 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
                         for (int i = 0; i < 4; ++i) as[i] = ldexp(a[i], -e);
                         sc = ldexp(1.0, -e);
                     }
-                    double x[4], y[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        x[k] = fma(U[12 + k], ab[3], fma(U[8 + k], ab[2], fma(U[4 + k], ab[1], U[k] * ab[0])));
-                        y[k] = fma(Ui[k * 4 + 3], as[3], fma(Ui[k * 4 + 2], as[2], fma(Ui[k * 4 + 1], as[1], Ui[k * 4] * as[0])));
-                    }
-                    contribute(node, x, y);
                     const double* ef = EF + (size_t)node * kGradEF;
-                    const double z0 = ef[0] * x[0], z1 = ef[1] * x[1], z2 = ef[2] * x[2], z3 = ef[3] * x[3];
+                    double w[4], x[4], y[4], z[4], r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = pi[i] * as[i];
+                    mulUt(w, y);
+                    mulUt(ab, x);
+                    contribute(ef, node, x, y);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) z[k] = ef[k] * x[k];
+                    mulU(z, r);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        ab[j] = sc * fma(Ui[12 + j], z3, fma(Ui[8 + j], z2, fma(Ui[4 + j], z1, Ui[j] * z0)));
+                        ab[j] = sc * pi[j] * r[j];
                         acc[j] = a[j];
                     }
-                } else if (op.code == OP_PUSH) {
+                } else if (op.x == OP_PUSH) {
                     --asp;
-                    const double* as_ = stack + ((size_t)asp * 4) * kGradBlock + tid;
-                    const double* slot = tape + (size_t)G.op_tape[ip] * 4 * kGradBlock;
+                    const double* as_ = astack + ((size_t)asp * 4) * kGradBlock;
+                    const double* slot = tape + (size_t)op.w * 4 * kGradBlock;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { ab[i] = as_[i * kGradBlock]; acc[i] = slot[i * kGradBlock]; }
                 } else {
-                    const double* slot = tape + (size_t)G.op_partner[ip] * 4 * kGradBlock;
-                    double* as_ = stack + ((size_t)asp * 4) * kGradBlock + tid;
+                    const double* slot = tape + (size_t)op.w * 4 * kGradBlock;
+                    double* as_ = astack + ((size_t)asp * 4) * kGradBlock;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const double S = slot[i * kGradBlock];
-                        acc[i] = acc[i] / S;                 // the partial that was multiplied by the parked one
+                        acc[i] *= lik_rcp(S);                // the partial that was multiplied by the parked one
                         as_[i * kGradBlock] = ab[i] * acc[i];
                         ab[i] *= S;
                     }
@@ -491,15 +552,16 @@ __global__ __launch_bounds__(kGradBlock) void locus_grad_kernel(GradParams G) {
                 double d = 0;
                 for (int k = 0; k < 4; ++k)
                     for (int l = 0; l < 4; ++l)
-                        d += Wt[k * 4 + l] * (eig[4 + j * 4 + l] - eig[4 + i * 4 + l]) * (pi[j] * eig[20 + k * 4 + i] - pi[i] * eig[20 + k * 4 + j]);
+                        d += Wt[k * 4 + l] * (eig[4 + j * 4 + l] - eig[4 + i * 4 + l]) * (pig[j] * eig[20 + k * 4 + i] - pig[i] * eig[20 + k * 4 + j]);
                 G.out_dexch[item * 6 + q] = d;
             }
         }
-        // d lnL / d log t_b = t_b * sum over waves; and its total
+        // d lnL / d log t_b = t_b * sum over waves and slots; and its total
         double part = 0.0;
         for (int b = tid; b < nn; b += kGradBlock) {
             double g = 0;
-            for (int w = 0; w < kGradWaves; ++w) g += gb[w * nn + b];
+            for (int w = 0; w < kGradWaves; ++w)
+                for (int s = 0; s < kGradSlots; ++s) g += gb[((size_t)w * nn + b) * kGradSlots + s];
             g *= EF[b * kGradEF + 10];
             if (G.out_dlogt) G.out_dlogt[item * nn + b] = g;
             part += g;

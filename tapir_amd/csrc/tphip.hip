@@ -87,7 +87,8 @@ struct tphip_plan {
     DevBuf<TreeOp> d_ops;
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
-    DevBuf<int32_t> d_tip_taxon, d_op_node, d_op_tape, d_op_partner;
+    DevBuf<int32_t> d_tip_taxon, d_op_node;
+    DevBuf<int4> d_lik_ops;   // {code, taxon, node, tape slot} per op for the locus likelihood / gradient kernels
     double* d_tape = nullptr;   // reverse-mode tape of locus_grad_kernel, grown on demand
     size_t tape_bytes = 0;
     double* d_col_weight = nullptr;  // optional column multiplicities for the locus likelihood / gradient kernels
@@ -130,7 +131,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_locus_pichunk_offsets.release(); plan->d_site_chunk_locus.release(); plan->d_site_chunk_index.release();
     plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
     plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
-    plan->d_op_tape.release(); plan->d_op_partner.release();
+    plan->d_lik_ops.release();
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
@@ -219,8 +220,15 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->nwords = (int32_t)((tip_taxon.size() + 7) / 8);
     if (e == hipSuccess) e = p->d_tip_taxon.upload(tip_taxon);
     if (e == hipSuccess) e = p->d_op_node.upload(p->prog.op_node);
-    if (e == hipSuccess) e = p->d_op_tape.upload(p->prog.op_tape);
-    if (e == hipSuccess) e = p->d_op_partner.upload(p->prog.op_partner);
+    if (e == hipSuccess) {
+        std::vector<int4> lops(p->prog.ops.size());
+        for (size_t i = 0; i < lops.size(); ++i) {
+            const int32_t code = p->prog.ops[i].code;
+            lops[i] = make_int4(code, p->prog.ops[i].taxon, p->prog.op_node[i],
+                                code == OP_POP_MUL ? p->prog.op_partner[i] : p->prog.op_tape[i]);
+        }
+        e = p->d_lik_ops.upload(lops);
+    }
     p->nnodes = d->nnodes;
     if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
     if (e == hipSuccess) e = p->d_offsets.upload(p->h_offsets);
@@ -534,11 +542,16 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
     LikParams L;
     L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;
     L.col_weight = p->d_col_weight;
-    L.ops = p->d_ops.p; L.op_node = p->d_op_node.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes;
+    L.lops = p->d_lik_ops.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes; L.ntaxa = p->ntaxa;
     L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
     L.cand_pfac = d_cand_pfac; L.out = d_out;
-    const size_t lds = ((size_t)p->nnodes * 16 + (size_t)p->prog.stack_depth * 4 * kLikBlock) * sizeof(double);
+    size_t lds = ((size_t)p->nnodes * 4 + (size_t)p->prog.stack_depth * 4 * kLikBlock) * sizeof(double);
+    const size_t stage = (size_t)p->ntaxa * kLikBlock;
+    // staging the state masks in LDS costs this kernel more than it saves (measured: 13.6 ms vs 10.0 ms per 1616
+    // candidates x 20000 columns x 64 taxa): its tip loads are already covered by other waves.  Opt-in for experiments.
+    L.stage_states = (getenv("TPHIP_LIK_STAGE") && stage <= 48 * 1024 && lds + stage <= 150 * 1024) ? 1 : 0;
+    if (L.stage_states) lds += stage;
     if (lds > 150 * 1024) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-likelihood kernel's LDS tables");
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
@@ -582,13 +595,17 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     LikParams& L = G.L;
     L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;
     L.col_weight = p->d_col_weight;
-    L.ops = p->d_ops.p; L.op_node = p->d_op_node.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes;
+    L.lops = p->d_lik_ops.p; L.nops = (int32_t)p->prog.ops.size(); L.nnodes = p->nnodes; L.ntaxa = p->ntaxa;
     L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
     L.cand_pfac = d_cand_pfac; L.out = d_lnl;
-    G.op_tape = p->d_op_tape.p; G.op_partner = p->d_op_partner.p; G.ntape = p->prog.ntape; G.ncand = ncand;
+    G.ntape = p->prog.ntape; G.ncand = ncand;
     G.out_dexch = d_dexch; G.out_dlogt = d_dlogt; G.out_sum_dlogt = d_sum_dlogt;
-    const size_t lds = ((size_t)p->nnodes * (16 + kGradEF + kGradWaves) + (size_t)p->prog.stack_depth * 4 * kGradBlock) * sizeof(double);
+    size_t lds = (size_t)p->nnodes * (kGradEF + kGradWaves * kGradSlots) * sizeof(double);
+    const size_t stage = (size_t)p->ntaxa * kGradBlock;
+    L.stage_states = (stage <= 48 * 1024 && lds + stage <= 150 * 1024) ? 1 : 0;
+    if (getenv("TPHIP_LIK_NO_STAGE")) L.stage_states = 0;
+    if (L.stage_states) lds += stage;
     if (lds > 150 * 1024) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-gradient kernel's LDS tables");
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
@@ -596,7 +613,15 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
         attr_set = true;
     }
     // resident workgroups loop over the candidates; each owns one tape
-    int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / std::max<size_t>(lds + 1024, 1)));
+    int blocks_per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, locus_grad_kernel, kGradBlock, lds) != hipSuccess || blocks_per_cu < 1)
+        blocks_per_cu = 1;
+    // the tape of the resident blocks should stay within reach of the 256 MB memory-side cache: with 64 taxa, 4 blocks
+    // per CU (390 MB of tape) ran slower than 3 (measured 91 vs 85 ms); fewer than 3 loses more to latency than it gains
+    {
+        const size_t tape_per_block = (size_t)std::max(1, p->prog.ntape + p->prog.stack_depth) * 4 * kGradBlock * sizeof(double);
+        if (tape_per_block * (size_t)p->num_cus * (size_t)blocks_per_cu > ((size_t)300 << 20)) blocks_per_cu = std::min(blocks_per_cu, 3);
+    }
     if (const char* env = getenv("TPHIP_GRAD_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(env));
     const int nsplit = lik_nsplit(p, ncand, kGradBlock);
     L.nsplit = nsplit;
@@ -610,7 +635,7 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
         G.out_dlogt = d_dlogt ? p->d_part + 8 * items : nullptr;
     }
     const int64_t grid = std::min<int64_t>((int64_t)items, (int64_t)p->num_cus * blocks_per_cu);
-    const size_t need = (size_t)grid * (size_t)std::max(1, p->prog.ntape) * 4 * kGradBlock * sizeof(double);
+    const size_t need = (size_t)grid * (size_t)std::max(1, p->prog.ntape + p->prog.stack_depth) * 4 * kGradBlock * sizeof(double);
     if (need > p->tape_bytes) {
         if (p->d_tape) { HIP_TRY(hipFree(p->d_tape)); p->d_tape = nullptr; p->tape_bytes = 0; }
         HIP_TRY(hipMalloc((void**)&p->d_tape, need));

@@ -257,8 +257,10 @@ class Stage1:
         best = grid[np.argmax(lnl, axis=1)]
         return best[:, None] * shape[None, :]
 
-    def fit_grm(self, maxit=300):
+    def fit_grm(self, maxit=None):
         L = self.plan.nloci
+        if maxit is None:
+            maxit = max(300, 4 * (5 + len(self.branches)))   # L-BFGS needs O(dimension) iterations on big trees
         x0 = np.zeros((L, 5 + len(self.branches)))
         x0[:, 5:] = np.log(self.initial_branch_lengths()[:, self.branches])
         lo = np.concatenate([np.full(5, LOG_RATE_MIN), np.full(len(self.branches), LOG_BLEN_MIN)])
