@@ -27,6 +27,7 @@ import numpy as np
 RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
 LOG_RATE_MIN, LOG_RATE_MAX = -12.0, 12.0    # exchangeabilities within [6e-6, 1.6e5] (HyPhy: [0, 10000])
 LOG_BLEN_MIN, LOG_BLEN_MAX = -30.0, 4.0     # branch lengths within [1e-13, 55]
+PRUNE_NATS = 30.0                           # see Stage1.fit_submodels
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
 
 
@@ -79,7 +80,8 @@ class _LBFGS:
     `value(X, idx)` evaluates points X[len(idx), D] of problems idx; `value_and_grad(X, idx)` adds gradients."""
 
     def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=1e-5,
-                 lo=-np.inf, hi=np.inf):
+                 lo=-np.inf, hi=np.inf, prune=None):
+        self.prune = prune   # optional: prune(problem indices, f, last decrease) -> mask of problems to abandon
         self.value, self.vg = value, value_and_grad
         self.x = np.array(x0, dtype=np.float64)
         P, D = self.x.shape
@@ -157,6 +159,8 @@ class _LBFGS:
             df = f[live] - fx
             done = failed | ((df <= self.ftol * (1.0 + np.abs(fx))) & (np.abs(gx).max(1) <= self.gtol * (1.0 + np.abs(fx))))
             done |= np.abs(gx).max(1) <= 1e-9
+            if self.prune is not None:
+                done |= self.prune(live, fx, df)
             self.x[live] = xnew; f[live] = fx; g[live] = gx
             self.iters[live] += 1
             converged[live[done]] = True
@@ -167,7 +171,8 @@ class _LBFGS:
 class Stage1:
     """Model-averaged exchangeabilities for every locus of a plan (see module docstring)."""
 
-    def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, analytic=None, sub_analytic=None, verbose=False):
+    def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, analytic=None, sub_analytic=None, prune_models=True,
+                 verbose=False):
         self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
         self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
         self.pi = self.pi / self.pi.sum(1, keepdims=True)
@@ -183,6 +188,7 @@ class Stage1:
         # which is what one reverse-mode gradient costs at present (measured, tools/stage1_timing.py), so they default
         # to the stencil; the general model (5 + 2N-3 parameters) always uses the gradient kernel
         self.sub_analytic = (analytic is True and sub_analytic is not False) if sub_analytic is None else sub_analytic
+        self.prune_models = prune_models
         self.ngrads = 0
         self.verbose = verbose
         self.nevals = 0
@@ -323,7 +329,7 @@ class Stage1:
         g = (f[:, 1::2] - f[:, 2::2]) / (2 * h)
         return f[:, 0], np.where(self._sub_active[idx], g, 0.0)
 
-    def fit_submodels(self, grm_exch, grm_t, maxit=100):
+    def fit_submodels(self, grm_exch, grm_t, maxit=100, grm_lnl=None):
         L = self.plan.nloci
         strings = model_strings()
         cls, k = model_design(strings)
@@ -341,8 +347,23 @@ class Stage1:
             inc = self._sub_cls == c
             cnt = inc.sum(1)
             x0[:, c] = np.where(cnt > 0, (lg * inc).sum(1) / np.maximum(cnt, 1), 0.0)
+        # Models that cannot matter are abandoned early: a model whose Akaike score lnL - k trails the best of its
+        # locus by more than PRUNE_NATS even after crediting three times its last improvement carries a weight below
+        # e^-30 ~ 1e-13 -- invisible in the averaged rates -- so polishing its optimum is wasted likelihood evaluations
+        # (with thousands of columns all but a handful of the 203 models are in that state after one iteration).
+        best = (np.asarray(grm_lnl) - 5.0).copy() if grm_lnl is not None else np.full(L, -np.inf)
+        self.pruned = 0
+
+        def prune(idx, f, df):
+            score = -f - kk[idx]
+            loc = self._sub_locus[idx]
+            np.maximum.at(best, loc, score)
+            drop = score + 3.0 * np.maximum(df, 0.0) < best[loc] - PRUNE_NATS
+            self.pruned += int(drop.sum())
+            return drop
+
         opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0, active=self._sub_active, maxit=maxit,
-                     lo=LOG_RATE_MIN, hi=LOG_RATE_MAX)
+                     lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune if self.prune_models else None)
         x, f = opt.run()
         self.sub_iters = opt.iters
         exch = self._sub_exch(x, self._sub_cls).reshape(L, M, 6)
@@ -351,7 +372,7 @@ class Stage1:
     # ---- model averaging (bf:806-847) --------------------------------------------------------------------
     def run(self):
         grm_exch, grm_t, grm_lnl = self.fit_grm()
-        sub_exch, sub_lnl, k = self.fit_submodels(grm_exch, grm_t)
+        sub_exch, sub_lnl, k = self.fit_submodels(grm_exch, grm_t, grm_lnl=grm_lnl)
         lnl = np.concatenate([grm_lnl[:, None], sub_lnl], axis=1)          # [L, 203]
         exch = np.concatenate([grm_exch[:, None, :], sub_exch], axis=1)    # [L, 203, 6]
         score = lnl - k[None, :]                                           # = -AIC/2 + const

@@ -44,8 +44,10 @@ def test_stage1_matches_independent_restatement():
         ref = stage1_oracle.model_averaged(st[:, l * n:(l + 1) * n], pin["parent"], blen, pin["leaf"], pi[l])
         assert np.max(np.abs(got["exch"][l] - ref["exch"]) / ref["exch"]) < 1e-3
         lnl = np.array([ref["lnl"][m] for m in got["models"]])
-        assert np.max(np.abs(lnl - got["lnl"][l])) < 1e-3
         w = np.array([ref["weights"][m] for m in got["models"]])
+        keep = w > 1e-9   # models abandoned early (weight < e^-30) are not polished to their optimum
+        assert np.max(np.abs(lnl - got["lnl"][l])[keep]) < 1e-3
+        assert np.all(got["lnl"][l] <= lnl + 1e-3)
         assert np.max(np.abs(w - got["weights"][l])) < 1e-4
 
 
@@ -105,10 +107,12 @@ def test_stage1_analytic_and_finite_difference_gradients_agree():
     blen = np.asarray(pin["blen"]) / pin["correction"]
     plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"],
                        [1], [[0, 1]], correction=pin["correction"])
-    a = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen, analytic=True)
-    b = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen, analytic=False)
+    a = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen, analytic=True, prune_models=False)
+    b = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen, analytic=False, prune_models=False)
+    c = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen)   # defaults: early abandoning on
     plan.close()
     assert a["ngrads"] > 0 and b["ngrads"] == 0
+    assert np.max(np.abs(c["exch"] - a["exch"]) / a["exch"]) < 1e-6 and c["nevals"] < b["nevals"]
     assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-3
     assert np.max(np.abs(a["lnl"] - b["lnl"])) < 1e-3
     assert np.max(np.abs(a["weights"] - b["weights"])) < 1e-4

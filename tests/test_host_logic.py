@@ -462,8 +462,10 @@ def test_stage1_optimiser_against_independent_restatement(tmp_path):
         ref = stage1_oracle.model_averaged(st[:, l * 120:(l + 1) * 120], pin["parent"], blen, pin["leaf"], pi[l])
         assert np.max(np.abs(got["exch"][l] - ref["exch"]) / ref["exch"]) < 1e-3
         lnl = np.array([ref["lnl"][m] for m in got["models"]])
-        assert np.max(np.abs(lnl - got["lnl"][l])) < 1e-3
         w = np.array([ref["weights"][m] for m in got["models"]])
+        keep = w > 1e-9   # models abandoned early (weight < e^-30) are not polished to their optimum
+        assert np.max(np.abs(lnl - got["lnl"][l])[keep]) < 1e-3
+        assert np.all(got["lnl"][l] <= lnl + 1e-3)
         assert np.max(np.abs(w - got["weights"][l])) < 1e-4
 
 
