@@ -176,11 +176,14 @@ int tphip_locus_loglik_dev(tphip_plan *plan, const uint8_t *d_states, int64_t nc
  * Candidates are described exactly as for tphip_locus_loglik_dev.  Outputs per candidate:
  *   d_lnl[c]; d_dexch[c][6] = d lnL / d (AC, AG, AT, CG, CT, GT) with branch lengths held fixed;
  *   d_dlogt[c][nnodes] = d lnL / d log t_b (root entry 0; may be NULL); d_sum_dlogt[c] = its sum over branches
- *   (the only branch-length derivative a rate-class model needs: bf:613-619 ties all lengths to one factor). */
+ *   (the only branch-length derivative a rate-class model needs: bf:613-619 ties all lengths to one factor);
+ *   d_d2logt[c][nnodes] = d2 lnL / d (log t_b)^2, the diagonal of the Hessian in the branch lengths (may be NULL;
+ *   the optimiser's preconditioner). */
 int tphip_locus_gradient_dev(tphip_plan *plan, const uint8_t *d_states, int64_t ncand, const int32_t *d_cand_locus,
                              const double *d_cand_exch, const double *d_blen_vecs, const int32_t *d_cand_vec,
                              const double *d_cand_scale, const int32_t *d_cand_pidx, const double *d_cand_pfac,
-                             double *d_lnl, double *d_dexch, double *d_dlogt, double *d_sum_dlogt, void *stream);
+                             double *d_lnl, double *d_dexch, double *d_dlogt, double *d_sum_dlogt, double *d_d2logt,
+                             void *stream);
 
 /* Profiling hooks for bench.py: when enabled the library brackets its dominant kernel (site rates) with
  * HIP events on the caller's stream and accumulates the elapsed time. */
@@ -221,11 +224,12 @@ int tphip_locus_loglik(tphip_plan *plan, const uint8_t *states, void **d_states_
                        const double *blen_vecs, int64_t ncand, const int32_t *cand_locus, const double *cand_exch,
                        const int32_t *cand_vec, const double *cand_scale, const int32_t *cand_pidx,
                        const double *cand_pfac, double *out);
-/* host-pointer twin of tphip_locus_gradient_dev (dlogt may be NULL) */
+/* host-pointer twin of tphip_locus_gradient_dev (dlogt and d2logt may be NULL) */
 int tphip_locus_gradient(tphip_plan *plan, const uint8_t *states, void **d_states_cache, int64_t nvec,
                          const double *blen_vecs, int64_t ncand, const int32_t *cand_locus, const double *cand_exch,
                          const int32_t *cand_vec, const double *cand_scale, const int32_t *cand_pidx,
-                         const double *cand_pfac, double *lnl, double *dexch, double *dlogt, double *sum_dlogt);
+                         const double *cand_pfac, double *lnl, double *dexch, double *dlogt, double *sum_dlogt,
+                         double *d2logt);
 int tphip_free_device(tphip_plan *plan, void *d_ptr);
 /* Column multiplicities [ncols] (host) for tphip_locus_loglik / tphip_locus_gradient of this plan: the plan's columns
  * are then site patterns (tphip_compress_columns) and every pattern's log-likelihood counts weight times.

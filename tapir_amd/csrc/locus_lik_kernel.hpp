@@ -292,6 +292,8 @@ struct GradParams {
     double* out_dexch;          // [items][6]   d lnL / d r  (AC, AG, AT, CG, CT, GT), branch lengths held fixed
     double* out_dlogt;          // [items][nnodes] d lnL / d log t_b, or null
     double* out_sum_dlogt;      // [items]
+    double* out_d2logt;         // [items][nnodes] d2 lnL / d (log t_b)^2 with everything else fixed (the diagonal of the
+                                // Hessian: preconditions the optimiser), or null
 };
 
 __device__ inline double lik_wave_sum(double v) {
@@ -313,14 +315,17 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
     const int nn = P.nnodes;
     double* EF = lds;                                   // [nn][kGradEF]
     double* gb = EF + (size_t)nn * kGradEF;             // [kGradWaves][nn][kGradSlots]
-    uint8_t* sts = (uint8_t*)(gb + (size_t)kGradWaves * nn * kGradSlots);   // [ntaxa][kGradBlock] when staged
+    double* hb = gb + (size_t)kGradWaves * nn * kGradSlots;                 // same shape: second derivatives
+    uint8_t* sts = (uint8_t*)(hb + (size_t)kGradWaves * nn * kGradSlots);   // [ntaxa][kGradBlock] when staged
     __shared__ double eig[36];
     __shared__ double tipY[16 * 4];
     __shared__ double red[kGradWaves * 18];
+    const bool want_h = G.out_d2logt != nullptr;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* tape = G.tape + (size_t)blockIdx.x * (size_t)(G.ntape + P.stack_depth) * 4 * kGradBlock + tid;
     double* astack = tape + (size_t)G.ntape * 4 * kGradBlock;
     double* gbw = gb + ((size_t)wave * nn) * kGradSlots + (lane & (kGradSlots - 1));
+    double* hbw = hb + ((size_t)wave * nn) * kGradSlots + (lane & (kGradSlots - 1));
     const int64_t nitems = G.ncand * P.nsplit;
     for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         __syncthreads();
@@ -332,6 +337,7 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
             if (tid == 0) { P.out[item] = 0.0; G.out_sum_dlogt[item] = 0.0; }
             if (tid < 6) G.out_dexch[item * 6 + tid] = 0.0;
             if (G.out_dlogt) for (int b = tid; b < nn; b += kGradBlock) G.out_dlogt[item * nn + b] = 0.0;
+            if (want_h) for (int b = tid; b < nn; b += kGradBlock) G.out_d2logt[item * nn + b] = 0.0;
             continue;
         }
         const double* pig = P.models[locus].pi;
@@ -356,7 +362,10 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
                 }
             EF[b * kGradEF + 10] = t;
             EF[b * kGradEF + 11] = 0.0;
-            for (int w = 0; w < kGradWaves * kGradSlots; ++w) gb[((size_t)(w / kGradSlots) * nn + b) * kGradSlots + (w % kGradSlots)] = 0.0;
+            for (int w = 0; w < kGradWaves * kGradSlots; ++w) {
+                gb[((size_t)(w / kGradSlots) * nn + b) * kGradSlots + (w % kGradSlots)] = 0.0;
+                hb[((size_t)(w / kGradSlots) * nn + b) * kGradSlots + (w % kGradSlots)] = 0.0;
+            }
         }
         if (tid < 64) {  // Y[mask] = U^-1 (0/1 vector of the state mask)
             const int m = tid >> 2, k = tid & 3;
@@ -372,6 +381,7 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
 #pragma unroll
         for (int k = 0; k < 4; ++k) { lam[k] = lik_uniform(eig[k]); pi[k] = lik_uniform(pig[k]); }
         double total = 0.0;
+        double inv_seedw = 0.0;   // 1 / column weight of the column in flight (0 for padding lanes)
         double W[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) W[i] = 0.0;
@@ -400,6 +410,10 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
             W[14] = fma(x[3] * f23, y[2], W[14]);     W[15] = fma(t, d3, W[15]);
             const double c = fma(lam[3], d3, fma(lam[2], d2, fma(lam[1], d1, lam[0] * d0)));
             atomicAdd(gbw + (size_t)node * kGradSlots, c);
+            if (want_h) {   // d2 log L / dt^2 of this column = L''/L - (L'/L)^2; the adjoint already carries weight / L
+                const double c2 = fma(lam[3] * lam[3], d3, fma(lam[2] * lam[2], d2, fma(lam[1] * lam[1], d1, lam[0] * lam[0] * d0)));
+                atomicAdd(hbw + (size_t)node * kGradSlots, c2 - c * c * inv_seedw);
+            }
         };
 
         for (int64_t base = lo; base < hi; base += kGradBlock) {
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
             total = fma(cw, log(Lc) + (double)scale * 0.6931471805599453, total);
             // ---------------- reverse ----------------
             const double seed = cw / Lc;   // padding lanes contribute exact zeros
+            inv_seedw = cw > 0.0 ? 1.0 / cw : 0.0;
             double ab[4] = {pi[0] * seed, pi[1] * seed, pi[2] * seed, pi[3] * seed};
             int asp = 0;
             nxt = P.lops[P.nops - 1];
@@ -562,7 +577,14 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
             double g = 0;
             for (int w = 0; w < kGradWaves; ++w)
                 for (int s = 0; s < kGradSlots; ++s) g += gb[((size_t)w * nn + b) * kGradSlots + s];
-            g *= EF[b * kGradEF + 10];
+            const double t = EF[b * kGradEF + 10];
+            if (want_h) {   // d2/d(log t)^2 = t^2 d2/dt^2 + t d/dt
+                double h = 0;
+                for (int w = 0; w < kGradWaves; ++w)
+                    for (int s = 0; s < kGradSlots; ++s) h += hb[((size_t)w * nn + b) * kGradSlots + s];
+                G.out_d2logt[item * nn + b] = t * (t * h + g);
+            }
+            g *= t;
             if (G.out_dlogt) G.out_dlogt[item * nn + b] = g;
             part += g;
         }

@@ -91,6 +91,11 @@ struct tphip_plan {
     DevBuf<int4> d_lik_ops;   // {code, taxon, node, tape slot} per op for the locus likelihood / gradient kernels
     double* d_tape = nullptr;   // reverse-mode tape of locus_grad_kernel, grown on demand
     size_t tape_bytes = 0;
+    // grow-only device arena + pinned host mirror for the host-pointer likelihood / gradient calls: the optimiser
+    // makes thousands of small calls, so they must not hipMalloc or issue a dozen pageable copies each
+    char* d_arena = nullptr;
+    char* h_arena = nullptr;
+    size_t arena_bytes = 0;
     double* d_col_weight = nullptr;  // optional column multiplicities for the locus likelihood / gradient kernels
     double* d_part = nullptr;   // per-slice partial sums of the locus likelihood / gradient kernels, grown on demand
     size_t part_bytes = 0;
@@ -135,6 +140,8 @@ int tphip_plan_destroy(tphip_plan* plan) {
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
+    if (plan->d_arena) { (void)hipFree(plan->d_arena); plan->d_arena = nullptr; }
+    if (plan->h_arena) { (void)hipHostFree(plan->h_arena); plan->h_arena = nullptr; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
     return TPHIP_OK;
@@ -584,7 +591,7 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
 int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand, const int32_t* d_cand_locus,
                              const double* d_cand_exch, const double* d_blen_vecs, const int32_t* d_cand_vec,
                              const double* d_cand_scale, const int32_t* d_cand_pidx, const double* d_cand_pfac, double* d_lnl,
-                             double* d_dexch, double* d_dlogt, double* d_sum_dlogt, void* stream) {
+                             double* d_dexch, double* d_dlogt, double* d_sum_dlogt, double* d_d2logt, void* stream) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
     if (ncand < 0 || (ncand && (!d_states || !d_cand_locus || !d_cand_exch || !d_blen_vecs || !d_cand_vec || !d_cand_scale ||
                                 !d_cand_pidx || !d_cand_pfac || !d_lnl || !d_dexch || !d_sum_dlogt)))
@@ -600,8 +607,8 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
     L.cand_pfac = d_cand_pfac; L.out = d_lnl;
     G.ntape = p->prog.ntape; G.ncand = ncand;
-    G.out_dexch = d_dexch; G.out_dlogt = d_dlogt; G.out_sum_dlogt = d_sum_dlogt;
-    size_t lds = (size_t)p->nnodes * (kGradEF + kGradWaves * kGradSlots) * sizeof(double);
+    G.out_dexch = d_dexch; G.out_dlogt = d_dlogt; G.out_sum_dlogt = d_sum_dlogt; G.out_d2logt = d_d2logt;
+    size_t lds = (size_t)p->nnodes * (kGradEF + 2 * kGradWaves * kGradSlots) * sizeof(double);
     const size_t stage = (size_t)p->ntaxa * kGradBlock;
     L.stage_states = (stage <= 48 * 1024 && lds + stage <= 150 * 1024) ? 1 : 0;
     if (getenv("TPHIP_LIK_NO_STAGE")) L.stage_states = 0;
@@ -627,12 +634,13 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     L.nsplit = nsplit;
     const size_t nn = (size_t)p->nnodes, items = (size_t)ncand * nsplit;
     if (nsplit > 1) {   // partials: lnl[items], sum[items], dexch[items][6], dlogt[items][nn]
-        int rc = grow_part(p, items * (8 + (d_dlogt ? nn : 0)) * sizeof(double));
+        int rc = grow_part(p, items * (8 + (d_dlogt ? nn : 0) + (d_d2logt ? nn : 0)) * sizeof(double));
         if (rc) return rc;
         L.out = p->d_part;
         G.out_sum_dlogt = p->d_part + items;
         G.out_dexch = p->d_part + 2 * items;
         G.out_dlogt = d_dlogt ? p->d_part + 8 * items : nullptr;
+        G.out_d2logt = d_d2logt ? p->d_part + (8 + (d_dlogt ? nn : 0)) * items : nullptr;
     }
     const int64_t grid = std::min<int64_t>((int64_t)items, (int64_t)p->num_cus * blocks_per_cu);
     const size_t need = (size_t)grid * (size_t)std::max(1, p->prog.ntape + p->prog.stack_depth) * 4 * kGradBlock * sizeof(double);
@@ -653,6 +661,7 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
         sum(G.out_sum_dlogt, d_sum_dlogt, 1);
         sum(G.out_dexch, d_dexch, 6);
         if (d_dlogt) sum(G.out_dlogt, d_dlogt, (int)nn);
+        if (d_d2logt) sum(G.out_d2logt, d_d2logt, (int)nn);
         HIP_TRY(hipGetLastError());
     }
     return TPHIP_OK;
@@ -829,6 +838,83 @@ int tphip_free_device(tphip_plan* p, void* d_ptr) {
     return TPHIP_OK;
 }
 
+// Candidate batch staged through the plan's arena: one pinned buffer, one H2D copy in, one D2H copy out.
+namespace {
+struct CandBatch {
+    size_t off_locus, off_exch, off_blen, off_vec, off_scale, off_pidx, off_pfac, in_bytes;
+    size_t off_out, out_bytes, total;
+};
+
+int arena_reserve(tphip_plan* p, size_t bytes) {
+    if (bytes <= p->arena_bytes) return TPHIP_OK;
+    const size_t want = std::max(bytes, p->arena_bytes * 2);
+    if (p->d_arena) { HIP_TRY(hipFree(p->d_arena)); p->d_arena = nullptr; }
+    if (p->h_arena) { HIP_TRY(hipHostFree(p->h_arena)); p->h_arena = nullptr; }
+    p->arena_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&p->d_arena, want));
+    HIP_TRY(hipHostMalloc((void**)&p->h_arena, want, hipHostMallocDefault));
+    p->arena_bytes = want;
+    return TPHIP_OK;
+}
+
+int check_candidates(const tphip_plan* p, int64_t nvec, int64_t ncand, const int32_t* cand_locus, const int32_t* cand_vec,
+                     const int32_t* cand_pidx) {
+    for (int64_t c = 0; c < ncand; ++c) {
+        if (cand_locus[c] < 0 || cand_locus[c] >= p->nloci) return fail(TPHIP_ERR_INVALID, "cand_locus out of range");
+        if (cand_vec[c] < 0 || cand_vec[c] >= nvec) return fail(TPHIP_ERR_INVALID, "cand_vec out of range");
+        if (cand_pidx[c] >= p->nnodes) return fail(TPHIP_ERR_INVALID, "cand_pidx out of range");
+    }
+    return TPHIP_OK;
+}
+
+// device copy of the alignment: the caller's cache, or a scratch buffer for this call
+int stage_alignment(tphip_plan* p, const uint8_t* states, void** d_states_cache, Scratch& S, uint8_t** d_s) {
+    const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
+    *d_s = d_states_cache ? (uint8_t*)*d_states_cache : nullptr;
+    if (*d_s) return TPHIP_OK;
+    if (d_states_cache) {
+        HIP_TRY(hipMalloc((void**)d_s, nb ? nb : 1));
+        *d_states_cache = *d_s;
+    } else {
+        *d_s = S.get<uint8_t>(nb);
+        if (!*d_s) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    }
+    HIP_TRY(hipMemcpy(*d_s, states, nb, hipMemcpyHostToDevice));
+    return TPHIP_OK;
+}
+
+int stage_candidates(tphip_plan* p, int64_t nvec, const double* blen_vecs, int64_t ncand, const int32_t* cand_locus,
+                     const double* cand_exch, const int32_t* cand_vec, const double* cand_scale, const int32_t* cand_pidx,
+                     const double* cand_pfac, size_t out_doubles, CandBatch* B) {
+    const size_t n = (size_t)ncand, nn = (size_t)p->nnodes;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    B->off_locus = take(sizeof(int32_t) * n);
+    B->off_exch = take(sizeof(double) * n * 6);
+    B->off_blen = take(sizeof(double) * (size_t)nvec * nn);
+    B->off_vec = take(sizeof(int32_t) * n);
+    B->off_scale = take(sizeof(double) * n);
+    B->off_pidx = take(sizeof(int32_t) * n);
+    B->off_pfac = take(sizeof(double) * n);
+    B->in_bytes = off;
+    B->off_out = take(sizeof(double) * out_doubles);
+    B->out_bytes = sizeof(double) * out_doubles;
+    B->total = off;
+    int rc = arena_reserve(p, B->total);
+    if (rc) return rc;
+    char* h = p->h_arena;
+    memcpy(h + B->off_locus, cand_locus, sizeof(int32_t) * n);
+    memcpy(h + B->off_exch, cand_exch, sizeof(double) * n * 6);
+    memcpy(h + B->off_blen, blen_vecs, sizeof(double) * (size_t)nvec * nn);
+    memcpy(h + B->off_vec, cand_vec, sizeof(int32_t) * n);
+    memcpy(h + B->off_scale, cand_scale, sizeof(double) * n);
+    memcpy(h + B->off_pidx, cand_pidx, sizeof(int32_t) * n);
+    memcpy(h + B->off_pfac, cand_pfac, sizeof(double) * n);
+    HIP_TRY(hipMemcpyAsync(p->d_arena, h, B->in_bytes, hipMemcpyHostToDevice, nullptr));
+    return TPHIP_OK;
+}
+}  // namespace
+
 int tphip_locus_loglik(tphip_plan* p, const uint8_t* states, void** d_states_cache, int64_t nvec, const double* blen_vecs,
                        int64_t ncand, const int32_t* cand_locus, const double* cand_exch, const int32_t* cand_vec,
                        const double* cand_scale, const int32_t* cand_pidx, const double* cand_pfac, double* out) {
@@ -836,105 +922,66 @@ int tphip_locus_loglik(tphip_plan* p, const uint8_t* states, void** d_states_cac
         (ncand && (!blen_vecs || !cand_locus || !cand_exch || !cand_vec || !cand_scale || !cand_pidx || !cand_pfac || !out)))
         return fail(TPHIP_ERR_INVALID, "null argument");
     if (ncand == 0) return TPHIP_OK;
-    for (int64_t c = 0; c < ncand; ++c) {
-        if (cand_locus[c] < 0 || cand_locus[c] >= p->nloci) return fail(TPHIP_ERR_INVALID, "cand_locus out of range");
-        if (cand_vec[c] < 0 || cand_vec[c] >= nvec) return fail(TPHIP_ERR_INVALID, "cand_vec out of range");
-        if (cand_pidx[c] >= p->nnodes) return fail(TPHIP_ERR_INVALID, "cand_pidx out of range");
-    }
+    int rc = check_candidates(p, nvec, ncand, cand_locus, cand_vec, cand_pidx);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(p->device));
     Scratch S;
-    const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
-    uint8_t* d_s = d_states_cache ? (uint8_t*)*d_states_cache : nullptr;
-    if (!d_s) {
-        if (d_states_cache) {
-            HIP_TRY(hipMalloc((void**)&d_s, nb ? nb : 1));
-            *d_states_cache = d_s;
-        } else {
-            d_s = S.get<uint8_t>(nb);
-            if (!d_s) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
-        }
-        HIP_TRY(hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice));
-    }
-    const size_t n = (size_t)ncand;
-    int32_t* d_l = S.get<int32_t>(n);
-    double* d_e = S.get<double>(n * 6);
-    double* d_b = S.get<double>((size_t)nvec * (size_t)p->nnodes);
-    int32_t* d_v = S.get<int32_t>(n);
-    double* d_sc = S.get<double>(n);
-    int32_t* d_pi = S.get<int32_t>(n);
-    double* d_pf = S.get<double>(n);
-    double* d_o = S.get<double>(n);
-    if (!d_l || !d_e || !d_b || !d_v || !d_sc || !d_pi || !d_pf || !d_o) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
-    HIP_TRY(hipMemcpy(d_l, cand_locus, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_e, cand_exch, sizeof(double) * n * 6, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_b, blen_vecs, sizeof(double) * (size_t)nvec * (size_t)p->nnodes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_v, cand_vec, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_sc, cand_scale, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_pi, cand_pidx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_pf, cand_pfac, sizeof(double) * n, hipMemcpyHostToDevice));
-    int rc = tphip_locus_loglik_dev(p, d_s, ncand, d_l, d_e, d_b, d_v, d_sc, d_pi, d_pf, d_o, nullptr);
+    uint8_t* d_s = nullptr;
+    rc = stage_alignment(p, states, d_states_cache, S, &d_s);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    CandBatch B;
+    rc = stage_candidates(p, nvec, blen_vecs, ncand, cand_locus, cand_exch, cand_vec, cand_scale, cand_pidx, cand_pfac,
+                          (size_t)ncand, &B);
+    if (rc) return rc;
+    char* d = p->d_arena;
+    rc = tphip_locus_loglik_dev(p, d_s, ncand, (const int32_t*)(d + B.off_locus), (const double*)(d + B.off_exch),
+                                (const double*)(d + B.off_blen), (const int32_t*)(d + B.off_vec),
+                                (const double*)(d + B.off_scale), (const int32_t*)(d + B.off_pidx),
+                                (const double*)(d + B.off_pfac), (double*)(d + B.off_out), nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(p->h_arena + B.off_out, d + B.off_out, B.out_bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    memcpy(out, p->h_arena + B.off_out, B.out_bytes);
     return TPHIP_OK;
 }
 
 int tphip_locus_gradient(tphip_plan* p, const uint8_t* states, void** d_states_cache, int64_t nvec, const double* blen_vecs,
                          int64_t ncand, const int32_t* cand_locus, const double* cand_exch, const int32_t* cand_vec,
                          const double* cand_scale, const int32_t* cand_pidx, const double* cand_pfac, double* lnl,
-                         double* dexch, double* dlogt, double* sum_dlogt) {
+                         double* dexch, double* dlogt, double* sum_dlogt, double* d2logt) {
     if (!p || !states || ncand < 0 || nvec < 0 ||
         (ncand && (!blen_vecs || !cand_locus || !cand_exch || !cand_vec || !cand_scale || !cand_pidx || !cand_pfac || !lnl ||
                    !dexch || !sum_dlogt)))
         return fail(TPHIP_ERR_INVALID, "null argument");
     if (ncand == 0) return TPHIP_OK;
-    for (int64_t c = 0; c < ncand; ++c) {
-        if (cand_locus[c] < 0 || cand_locus[c] >= p->nloci) return fail(TPHIP_ERR_INVALID, "cand_locus out of range");
-        if (cand_vec[c] < 0 || cand_vec[c] >= nvec) return fail(TPHIP_ERR_INVALID, "cand_vec out of range");
-        if (cand_pidx[c] >= p->nnodes) return fail(TPHIP_ERR_INVALID, "cand_pidx out of range");
-    }
+    int rc = check_candidates(p, nvec, ncand, cand_locus, cand_vec, cand_pidx);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(p->device));
     Scratch S;
-    const size_t nb = (size_t)p->ncols * (size_t)p->ntaxa;
-    uint8_t* d_s = d_states_cache ? (uint8_t*)*d_states_cache : nullptr;
-    if (!d_s) {
-        if (d_states_cache) {
-            HIP_TRY(hipMalloc((void**)&d_s, nb ? nb : 1));
-            *d_states_cache = d_s;
-        } else {
-            d_s = S.get<uint8_t>(nb);
-            if (!d_s) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
-        }
-        HIP_TRY(hipMemcpy(d_s, states, nb, hipMemcpyHostToDevice));
-    }
-    const size_t n = (size_t)ncand, nn = (size_t)p->nnodes;
-    int32_t* d_l = S.get<int32_t>(n);
-    double* d_e = S.get<double>(n * 6);
-    double* d_b = S.get<double>((size_t)nvec * nn);
-    int32_t* d_v = S.get<int32_t>(n);
-    double* d_sc = S.get<double>(n);
-    int32_t* d_pi = S.get<int32_t>(n);
-    double* d_pf = S.get<double>(n);
-    double* d_o = S.get<double>(n);
-    double* d_de = S.get<double>(n * 6);
-    double* d_dt = dlogt ? S.get<double>(n * nn) : nullptr;
-    double* d_st = S.get<double>(n);
-    if (!d_l || !d_e || !d_b || !d_v || !d_sc || !d_pi || !d_pf || !d_o || !d_de || !d_st || (dlogt && !d_dt))
-        return fail(TPHIP_ERR_HIP, "hipMalloc failed");
-    HIP_TRY(hipMemcpy(d_l, cand_locus, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_e, cand_exch, sizeof(double) * n * 6, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_b, blen_vecs, sizeof(double) * (size_t)nvec * nn, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_v, cand_vec, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_sc, cand_scale, sizeof(double) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_pi, cand_pidx, sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_pf, cand_pfac, sizeof(double) * n, hipMemcpyHostToDevice));
-    int rc = tphip_locus_gradient_dev(p, d_s, ncand, d_l, d_e, d_b, d_v, d_sc, d_pi, d_pf, d_o, d_de, d_dt, d_st, nullptr);
+    uint8_t* d_s = nullptr;
+    rc = stage_alignment(p, states, d_states_cache, S, &d_s);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(lnl, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dexch, d_de, sizeof(double) * n * 6, hipMemcpyDeviceToHost));
-    if (dlogt) HIP_TRY(hipMemcpy(dlogt, d_dt, sizeof(double) * n * nn, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(sum_dlogt, d_st, sizeof(double) * n, hipMemcpyDeviceToHost));
+    const size_t n = (size_t)ncand, nn = (size_t)p->nnodes;
+    CandBatch B;   // outputs: lnl[n] | sum_dlogt[n] | dexch[6n] | dlogt[n * nn] (optional) | d2logt[n * nn] (optional)
+    rc = stage_candidates(p, nvec, blen_vecs, ncand, cand_locus, cand_exch, cand_vec, cand_scale, cand_pidx, cand_pfac,
+                          n * (8 + (dlogt ? nn : 0) + (d2logt ? nn : 0)), &B);
+    if (rc) return rc;
+    char* d = p->d_arena;
+    double* d_o = (double*)(d + B.off_out);
+    rc = tphip_locus_gradient_dev(p, d_s, ncand, (const int32_t*)(d + B.off_locus), (const double*)(d + B.off_exch),
+                                  (const double*)(d + B.off_blen), (const int32_t*)(d + B.off_vec),
+                                  (const double*)(d + B.off_scale), (const int32_t*)(d + B.off_pidx),
+                                  (const double*)(d + B.off_pfac), d_o, d_o + 2 * n, dlogt ? d_o + 8 * n : nullptr, d_o + n,
+                                  d2logt ? d_o + (8 + (dlogt ? nn : 0)) * n : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(p->h_arena + B.off_out, d + B.off_out, B.out_bytes, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    const double* h_o = (const double*)(p->h_arena + B.off_out);
+    memcpy(lnl, h_o, sizeof(double) * n);
+    memcpy(sum_dlogt, h_o + n, sizeof(double) * n);
+    memcpy(dexch, h_o + 2 * n, sizeof(double) * n * 6);
+    if (dlogt) memcpy(dlogt, h_o + 8 * n, sizeof(double) * n * nn);
+    if (d2logt) memcpy(d2logt, h_o + (8 + (dlogt ? nn : 0)) * n, sizeof(double) * n * nn);
     return TPHIP_OK;
 }
 

@@ -51,7 +51,7 @@ SYMBOLS = [
     ("tphip_townsend_pi_dense_dev", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     ("tphip_quad_townsend_dev", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp, _vp]),
     ("tphip_locus_loglik_dev", ctypes.c_int, [_vp, _vp, _i64] + [_vp] * 9),
-    ("tphip_locus_gradient_dev", ctypes.c_int, [_vp, _vp, _i64] + [_vp] * 12),
+    ("tphip_locus_gradient_dev", ctypes.c_int, [_vp, _vp, _i64] + [_vp] * 13),
     ("tphip_state_histogram_dev", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     ("tphip_profile_enable", ctypes.c_int, [_vp, _i32]),
     ("tphip_profile_read", ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_f64), ctypes.POINTER(_i64), _i32]),
@@ -66,7 +66,7 @@ SYMBOLS = [
     ("tphip_locus_loglik", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 7),
     ("tphip_plan_set_column_weights", ctypes.c_int, [_vp, _vp]),
     ("tphip_compress_columns", ctypes.c_int, [ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    ("tphip_locus_gradient", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 10),
+    ("tphip_locus_gradient", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 11),
     ("tphip_free_device", ctypes.c_int, [_vp, _vp]),
 ]
 
@@ -231,9 +231,10 @@ class Plan:
         return out
 
     def locus_gradient(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
-                       cand_pfac=None, cache=None, per_branch=True):
+                       cand_pfac=None, cache=None, per_branch=True, curvature=False):
         """locus_loglik plus its derivatives (tphip_locus_gradient): returns (lnl[n], dexch[n, 6], dlogt[n, nnodes] or
-        None, sum_dlogt[n]); dexch holds branch lengths fixed, dlogt is d lnL / d log t_b."""
+        None, sum_dlogt[n]) and, with curvature=True, a fifth item d2logt[n, nnodes]; dexch holds branch lengths
+        fixed, dlogt is d lnL / d log t_b, d2logt the matching second derivatives (Hessian diagonal)."""
         states = _np(states, np.uint8)
         bv = _np(blen_vecs, np.float64)
         bv = bv.reshape(-1, bv.shape[-1])
@@ -246,12 +247,13 @@ class Plan:
         cf = _np(np.ones(n) if cand_pfac is None else cand_pfac, np.float64).reshape(n)
         lnl, dex, st = np.empty(n), np.empty((n, 6)), np.empty(n)
         dlt = np.empty((n, bv.shape[1])) if per_branch else None
+        d2 = np.empty((n, bv.shape[1])) if curvature else None
         ref = ctypes.byref(cache.ptr) if cache is not None else None
         _check(self._lib.tphip_locus_gradient(self._h, states.ctypes.data, ref, bv.shape[0], bv.ctypes.data, n, cl.ctypes.data,
                                               ce.ctypes.data, cv.ctypes.data, cs.ctypes.data, ci.ctypes.data, cf.ctypes.data,
                                               lnl.ctypes.data, dex.ctypes.data, dlt.ctypes.data if per_branch else None,
-                                              st.ctypes.data))
-        return lnl, dex, dlt, st
+                                              st.ctypes.data, d2.ctypes.data if curvature else None))
+        return (lnl, dex, dlt, st, d2) if curvature else (lnl, dex, dlt, st)
 
     def set_column_weights(self, weights):
         """Column multiplicities for locus_loglik / locus_gradient (site-pattern counts); None removes them."""

@@ -27,6 +27,7 @@ import numpy as np
 RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
 LOG_RATE_MIN, LOG_RATE_MAX = -12.0, 12.0    # exchangeabilities within [6e-6, 1.6e5] (HyPhy: [0, 10000])
 LOG_BLEN_MIN, LOG_BLEN_MAX = -30.0, 4.0     # branch lengths within [1e-13, 55]
+MAX_LOG_STEP = 2.0                          # largest move of a log-parameter in one iteration
 PRUNE_NATS = 30.0                           # see Stage1.fit_submodels
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
 
@@ -79,7 +80,7 @@ class _LBFGS:
     """Batched L-BFGS (maximisation written as minimisation of -lnL) over P independent problems of dimension D.
     `value(X, idx)` evaluates points X[len(idx), D] of problems idx; `value_and_grad(X, idx)` adds gradients."""
 
-    def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=1e-5,
+    def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=2e-6,
                  lo=-np.inf, hi=np.inf, prune=None):
         self.prune = prune   # optional: prune(problem indices, f, last decrease) -> mask of problems to abandon
         self.value, self.vg = value, value_and_grad
@@ -89,11 +90,16 @@ class _LBFGS:
         self.active = np.ones((P, D), bool) if active is None else active
         self.m, self.maxit, self.ftol, self.gtol = history, maxit, ftol, gtol
 
+    def _vg(self, x, idx):
+        out = self.vg(x, idx)
+        return out if len(out) == 3 else (out[0], out[1], None)
+
     def run(self):
         P, D = self.x.shape
         live = np.arange(P)
-        f, g = self.vg(self.x, live)
+        f, g, hd = self._vg(self.x, live)
         g = np.where(self.active, g, 0.0)
+        hdiag = np.full((P, D), np.nan) if hd is None else hd    # per-parameter curvature (NaN: unknown)
         S = np.zeros((self.m, P, D)); Y = np.zeros((self.m, P, D)); rho = np.zeros((self.m, P))
         nhist = np.zeros(P, dtype=np.int64)
         converged = np.zeros(P, bool)
@@ -114,21 +120,26 @@ class _LBFGS:
             sy = (S[last, live] * Y[last, live]).sum(1)
             yy = (Y[last, live] * Y[last, live]).sum(1)
             gamma = np.where((nhist[live] > 0) & (yy > 0), sy / np.maximum(yy, 1e-300), 1.0)
-            r = gamma[:, None] * q
+            # initial inverse Hessian: 1 / curvature where the objective supplies a positive one (the gradient kernel's
+            # Hessian diagonal for the branch lengths), the usual sy/yy scalar elsewhere
+            hl = hdiag[live]
+            r = np.where(np.isfinite(hl) & (hl > 1e-12), 1.0 / np.where(hl > 1e-12, hl, 1.0), gamma[:, None]) * q
             for i in range(self.m):
                 use = i >= self.m - nhist[live]
                 b = np.where(use, rho[i, live] * (Y[i, live] * r).sum(1), 0.0)
                 r += (alpha[i] - b)[:, None] * S[i, live]
-            d = -r
-            gd = (g[live] * d).sum(1)
+            d = np.clip(-r, -MAX_LOG_STEP, MAX_LOG_STEP)   # per coordinate: one runaway parameter (a branch collapsing
+            gd = (g[live] * d).sum(1)                      # to zero has almost no curvature) must not shrink the others' step
             bad = ~(gd < 0)
             d[bad] = -g[live][bad]
             gd[bad] = -(g[live][bad] ** 2).sum(1)
             # first iteration: a cautious step length
-            step0 = np.where(nhist[live] == 0, np.minimum(1.0, 1.0 / np.maximum(np.abs(g[live]).max(1), 1e-300)), 1.0)
+            have_h = np.isfinite(hl).any(axis=1)
+            step0 = np.where((nhist[live] == 0) & ~have_h,
+                             np.minimum(1.0, 1.0 / np.maximum(np.abs(g[live]).max(1), 1e-300)), 1.0)
             # cap the step in log-parameter space
             dmax = np.abs(d).max(1)
-            step0 = np.minimum(step0, 2.0 / np.maximum(dmax, 1e-300))
+            step0 = np.minimum(step0, MAX_LOG_STEP / np.maximum(dmax, 1e-300))
             t = step0.copy()
             xnew = self.x[live].copy(); fnew = f[live].copy()
             pending = np.arange(live.size)
@@ -145,8 +156,10 @@ class _LBFGS:
                 t[pending] *= 0.5
             failed = np.zeros(live.size, bool)
             failed[pending] = True  # no decrease found: treat as converged at the current point
-            fx, gx = self.vg(xnew, live)
+            fx, gx, hx = self._vg(xnew, live)
             gx = np.where(self.active[live], gx, 0.0)
+            if hx is not None:
+                hdiag[live] = hx
             s_ = xnew - self.x[live]
             y_ = gx - g[live]
             sy = (s_ * y_).sum(1)
@@ -172,7 +185,7 @@ class Stage1:
     """Model-averaged exchangeabilities for every locus of a plan (see module docstring)."""
 
     def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, analytic=None, sub_analytic=None, prune_models=True,
-                 verbose=False):
+                 precondition=True, verbose=False):
         self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
         self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
         self.pi = self.pi / self.pi.sum(1, keepdims=True)
@@ -189,6 +202,7 @@ class Stage1:
         # to the stencil; the general model (5 + 2N-3 parameters) always uses the gradient kernel
         self.sub_analytic = (analytic is True and sub_analytic is not False) if sub_analytic is None else sub_analytic
         self.prune_models = prune_models
+        self.precondition = precondition
         self.ngrads = 0
         self.verbose = verbose
         self.nevals = 0
@@ -208,29 +222,47 @@ class Stage1:
         return np.stack([r[..., 0], np.ones_like(r[..., 0]), r[..., 1], r[..., 2], r[..., 3], r[..., 4]], axis=-1)
 
     # ---- general reversible model: 5 rates + all branch lengths -------------------------------------------
-    def _grm_value(self, X, idx):
+    # The optimiser's coordinates are (log rates, log b) with b_b = t_b * totalFactor(r) the branch length in expected
+    # substitutions: at fixed b a change of the rates does not change how much evolution the tree carries, which
+    # removes the strong rates-vs-lengths correlation of the raw (r, t) coordinates (what Q normalisation does in
+    # most phylogenetics codes; HyPhy's script leaves Q unnormalised, bf:405-463, so t is what it reports).
+    def _grm_point(self, X, idx):
+        exch = self._exch_from_free(X[:, :5])
+        scale = 1.0 / total_factor(self.pi[idx], exch)
         vecs = np.zeros((len(idx), self.nn))
         vecs[:, self.branches] = np.exp(X[:, 5:])
-        return -self._lik(vecs, idx, self._exch_from_free(X[:, :5]))
+        return exch, scale, vecs
+
+    def _grm_value(self, X, idx):
+        exch, scale, vecs = self._grm_point(X, idx)
+        return -self._lik(vecs, idx, exch, None, scale)
 
     def _grm_value_and_grad(self, X, idx):
         n, D = X.shape
         if self.analytic:
-            vecs = np.zeros((n, self.nn))
-            vecs[:, self.branches] = np.exp(X[:, 5:])
-            exch = self._exch_from_free(X[:, :5])
+            exch, scale, vecs = self._grm_point(X, idx)
             self.ngrads += n
-            lnl, dex, dlt, _ = self.plan.locus_gradient(self.states, vecs, idx, exch, cache=self.cache)
+            out = self.plan.locus_gradient(self.states, vecs, idx, exch, None, scale, cache=self.cache,
+                                           curvature=self.precondition)
+            lnl, dex, dlt, sdl = out[:4]
+            # t_b = b_b / totalFactor(r): d log t_b / d r_q = -(2 pi_i pi_j) / totalFactor for every branch
+            pi = self.pi[idx]
+            dk = np.stack([2.0 * pi[:, i] * pi[:, j] for i, j in _PAIRS], axis=1)
+            dr = (dex - sdl[:, None] * dk * scale[:, None]) * exch        # d lnL / d log r_q at fixed b
             g = np.empty((n, D))
-            g[:, :5] = dex[:, [0, 2, 3, 4, 5]] * exch[:, [0, 2, 3, 4, 5]]     # d/d log r = r d/dr
-            g[:, 5:] = dlt[:, self.branches]
-            return -lnl, -g
+            g[:, :5] = dr[:, [0, 2, 3, 4, 5]]
+            g[:, 5:] = dlt[:, self.branches]                              # d/d log b_b = d/d log t_b
+            if not self.precondition:
+                return -lnl, -g
+            h = np.full((n, D), np.nan)
+            h[:, 5:] = -out[4][:, self.branches]   # curvature of -lnL in log b_b; the five rates get the scalar scaling
+            return -lnl, -g, h
         nb = len(self.branches)
         h = self.h
         vecs = np.zeros((n, self.nn))
         vecs[:, self.branches] = np.exp(X[:, 5:])
-        # candidates per problem: base, +-h on each log-rate (exchangeabilities change), +-h on each log-branch
-        # (the kernel multiplies one branch of the shared vector by exp(+-h))
+        # candidates per problem: base, +-h on each log-rate (exchangeabilities and the scale 1/totalFactor change),
+        # +-h on each log-branch (the kernel multiplies one branch of the shared vector by exp(+-h))
         per = 1 + 2 * D
         loc = np.repeat(idx, per)
         vec = np.repeat(np.arange(n), per)
@@ -243,7 +275,9 @@ class Stage1:
         for b in range(nb):
             pidx[:, 1 + 2 * (5 + b)] = self.branches[b]; pfac[:, 1 + 2 * (5 + b)] = np.exp(h)
             pidx[:, 2 + 2 * (5 + b)] = self.branches[b]; pfac[:, 2 + 2 * (5 + b)] = np.exp(-h)
-        f = -self._lik(vecs, loc, self._exch_from_free(logr.reshape(-1, 5)), vec, None, pidx.reshape(-1), pfac.reshape(-1))
+        exch = self._exch_from_free(logr.reshape(-1, 5))
+        scale = 1.0 / total_factor(self.pi[loc], exch)
+        f = -self._lik(vecs, loc, exch, vec, scale, pidx.reshape(-1), pfac.reshape(-1))
         f = f.reshape(n, per)
         g = (f[:, 1::2] - f[:, 2::2]) / (2 * h)
         return f[:, 0], g
@@ -268,7 +302,7 @@ class Stage1:
         if maxit is None:
             maxit = max(300, 4 * (5 + len(self.branches)))   # L-BFGS needs O(dimension) iterations on big trees
         x0 = np.zeros((L, 5 + len(self.branches)))
-        x0[:, 5:] = np.log(self.initial_branch_lengths()[:, self.branches])
+        x0[:, 5:] = np.log(self.initial_branch_lengths()[:, self.branches] * total_factor(self.pi, np.ones(6))[:, None])
         lo = np.concatenate([np.full(5, LOG_RATE_MIN), np.full(len(self.branches), LOG_BLEN_MIN)])
         hi = np.concatenate([np.full(5, LOG_RATE_MAX), np.full(len(self.branches), LOG_BLEN_MAX)])
         opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi)
@@ -276,7 +310,7 @@ class Stage1:
         self.grm_iters = opt.iters
         exch = self._exch_from_free(x[:, :5])
         t = np.zeros((L, self.nn))
-        t[:, self.branches] = np.exp(x[:, 5:])
+        t[:, self.branches] = np.exp(x[:, 5:]) / total_factor(self.pi, exch)[:, None]
         return exch, t, -f
 
     # ---- the 202 constrained models ---------------------------------------------------------------------

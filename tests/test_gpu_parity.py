@@ -578,3 +578,36 @@ def test_compress_columns_exact_and_weighted_likelihood(oracle):
     assert one[0].shape == (3, 1) and one[2][0] == 1
     same = engine.compress_columns(np.tile(np.array([[1], [2], [4]], np.uint8), (1, 1000)), [0, 400, 1000])
     assert same[0].shape == (3, 2) and list(same[2]) == [400, 600] and list(same[1]) == [0, 1, 2]
+
+
+def test_locus_gradient_hessian_diagonal(oracle):
+    """d2 lnL / d (log t_b)^2 from the gradient kernel against second central differences of the oracle likelihood."""
+    engine = _engine()
+    from tapir_amd import synth
+    rng = np.random.default_rng(5)
+    ntaxa = 10
+    d = synth.simulate(2, 400, ntaxa, 91, rate_mean=0.01)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    off = d["locus_offsets"]
+    plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, d["pi"], d["exch"], 3, [1], [[0, 1]])
+    parent = np.asarray(pin["parent"])
+    ce = np.exp(rng.normal(0, 0.4, (2, 6)))
+    cb = np.asarray(pin["blen"])[None, :] * np.exp(rng.normal(0, 0.5, (2, len(parent)))) * 0.02
+    w = rng.integers(1, 4, st.shape[1]).astype(float)
+    for weights in (None, w):
+        plan.set_column_weights(weights)
+        lnl, dex, dlt, sdl, d2 = plan.locus_gradient(st, cb, [0, 1], ce, curvature=True)
+        for c in range(2):
+            cols = slice(off[c], off[c + 1])
+            reps = np.ones(400, dtype=int) if weights is None else w[cols].astype(int)
+            stc = np.repeat(st[:, cols], reps, axis=1)       # the oracle has no weights: repeat the columns
+            f = lambda b: oracle.locus_loglik(stc, parent, b, pin["leaf"], d["pi"][c], ce[c])
+            h = 1e-3
+            for b in np.flatnonzero(parent >= 0)[::3]:
+                bp, bm = cb[c].copy(), cb[c].copy()
+                bp[b] *= np.exp(h)
+                bm[b] *= np.exp(-h)
+                ref = (f(bp) - 2 * f(cb[c]) + f(bm)) / (h * h)
+                assert abs(d2[c, b] - ref) < 1e-4 * max(1.0, abs(ref)), (c, b, d2[c, b], ref)
+    plan.close()

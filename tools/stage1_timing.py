@@ -13,7 +13,8 @@ pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, d["locus_o
 plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"], [1], [[0, 1]],
                    correction=pin["correction"])
 analytic = None if len(sys.argv) < 5 else (sys.argv[4] == "analytic")
-s1 = stage1.Stage1(plan, st, pi, pin["parent"], np.asarray(pin["blen"]) / pin["correction"], analytic=analytic)
+s1 = stage1.Stage1(plan, st, pi, pin["parent"], np.asarray(pin["blen"]) / pin["correction"], analytic=analytic,
+                   precondition=os.environ.get("S1_NO_PRECOND") is None)
 t0 = time.time(); ge, gt, gl = s1.fit_grm(); t1 = time.time()
 e1, g1 = s1.nevals, s1.ngrads
 sub = s1.fit_submodels(ge, gt, grm_lnl=gl); t2 = time.time()
