@@ -100,7 +100,11 @@ class _LBFGS:
         f, g, hd = self._vg(self.x, live)
         g = np.where(self.active, g, 0.0)
         hdiag = np.full((P, D), np.nan) if hd is None else hd    # per-parameter curvature (NaN: unknown)
-        S = np.zeros((self.m, P, D)); Y = np.zeros((self.m, P, D)); rho = np.zeros((self.m, P))
+        # correction pairs in a ring shared by all problems: slot it % m holds the pair of iteration it, rho = 0 marks
+        # "no pair" (problem not live, or curvature condition failed), which makes the two-loop skip it
+        m = self.m
+        S = np.zeros((m, P, D)); Y = np.zeros((m, P, D)); rho = np.zeros((m, P))
+        gamma_all = np.ones(P)
         nhist = np.zeros(P, dtype=np.int64)
         converged = np.zeros(P, bool)
         self.iters = np.zeros(P, dtype=np.int64)
@@ -108,47 +112,48 @@ class _LBFGS:
             live = np.flatnonzero(~converged)
             if live.size == 0:
                 break
-            # two-loop recursion on the live problems
-            q = g[live].copy()
-            alpha = np.zeros((self.m, live.size))
-            for i in range(self.m - 1, -1, -1):
-                use = i >= self.m - nhist[live]
-                a = np.where(use, rho[i, live] * (S[i, live] * q).sum(1), 0.0)
+            all_live = live.size == P
+            sl = slice(None) if all_live else live
+            xl, fl, gl = self.x[sl], f[sl], g[sl]
+            # two-loop recursion on the live problems, newest pair first
+            slots = [(it - 1 - j) % m for j in range(min(it, m))]
+            q = gl.copy()
+            alpha = {}
+            for i in slots:
+                a = rho[i, sl] * np.einsum("pd,pd->p", S[i, sl], q)
                 alpha[i] = a
-                q -= a[:, None] * Y[i, live]
-            last = self.m - 1
-            sy = (S[last, live] * Y[last, live]).sum(1)
-            yy = (Y[last, live] * Y[last, live]).sum(1)
-            gamma = np.where((nhist[live] > 0) & (yy > 0), sy / np.maximum(yy, 1e-300), 1.0)
+                q -= a[:, None] * Y[i, sl]
+            gamma = gamma_all[sl]
             # initial inverse Hessian: 1 / curvature where the objective supplies a positive one (the gradient kernel's
             # Hessian diagonal for the branch lengths), the usual sy/yy scalar elsewhere
-            hl = hdiag[live]
-            r = np.where(np.isfinite(hl) & (hl > 1e-12), 1.0 / np.where(hl > 1e-12, hl, 1.0), gamma[:, None]) * q
-            for i in range(self.m):
-                use = i >= self.m - nhist[live]
-                b = np.where(use, rho[i, live] * (Y[i, live] * r).sum(1), 0.0)
-                r += (alpha[i] - b)[:, None] * S[i, live]
-            d = np.clip(-r, -MAX_LOG_STEP, MAX_LOG_STEP)   # per coordinate: one runaway parameter (a branch collapsing
-            gd = (g[live] * d).sum(1)                      # to zero has almost no curvature) must not shrink the others' step
-            bad = ~(gd < 0)
-            d[bad] = -g[live][bad]
-            gd[bad] = -(g[live][bad] ** 2).sum(1)
-            # first iteration: a cautious step length
+            hl = hdiag[sl]
             have_h = np.isfinite(hl).any(axis=1)
-            step0 = np.where((nhist[live] == 0) & ~have_h,
-                             np.minimum(1.0, 1.0 / np.maximum(np.abs(g[live]).max(1), 1e-300)), 1.0)
+            if have_h.any():
+                r = np.where(np.isfinite(hl) & (hl > 1e-12), 1.0 / np.where(hl > 1e-12, hl, 1.0), gamma[:, None]) * q
+            else:
+                r = gamma[:, None] * q
+            for i in reversed(slots):
+                bcoef = rho[i, sl] * np.einsum("pd,pd->p", Y[i, sl], r)
+                r += (alpha[i] - bcoef)[:, None] * S[i, sl]
+            d = np.clip(-r, -MAX_LOG_STEP, MAX_LOG_STEP)   # per coordinate: one runaway parameter (a branch collapsing
+            gd = np.einsum("pd,pd->p", gl, d)              # to zero has almost no curvature) must not shrink the others' step
+            bad = ~(gd < 0)
+            if bad.any():
+                d[bad] = -gl[bad]
+                gd[bad] = -(gl[bad] ** 2).sum(1)
+            # first iteration: a cautious step length
+            step0 = np.where((nhist[sl] == 0) & ~have_h, np.minimum(1.0, 1.0 / np.maximum(np.abs(gl).max(1), 1e-300)), 1.0)
             # cap the step in log-parameter space
             dmax = np.abs(d).max(1)
-            step0 = np.minimum(step0, MAX_LOG_STEP / np.maximum(dmax, 1e-300))
-            t = step0.copy()
-            xnew = self.x[live].copy(); fnew = f[live].copy()
+            t = np.minimum(step0, MAX_LOG_STEP / np.maximum(dmax, 1e-300))
+            xnew = xl.copy(); fnew = fl.copy()
             pending = np.arange(live.size)
             for _ in range(30):
                 if pending.size == 0:
                     break
-                xt = np.clip(self.x[live][pending] + t[pending, None] * d[pending], self.lo, self.hi)
+                xt = np.clip(xl[pending] + t[pending, None] * d[pending], self.lo, self.hi)
                 ft = self.value(xt, live[pending])
-                ok = ft <= f[live][pending] + 1e-4 * t[pending] * gd[pending]
+                ok = ft <= fl[pending] + 1e-4 * t[pending] * gd[pending]
                 ok &= np.isfinite(ft)
                 acc = pending[ok]
                 xnew[acc] = xt[ok]; fnew[acc] = ft[ok]
@@ -157,25 +162,28 @@ class _LBFGS:
             failed = np.zeros(live.size, bool)
             failed[pending] = True  # no decrease found: treat as converged at the current point
             fx, gx, hx = self._vg(xnew, live)
-            gx = np.where(self.active[live], gx, 0.0)
+            gx = np.where(self.active[sl], gx, 0.0)
             if hx is not None:
-                hdiag[live] = hx
-            s_ = xnew - self.x[live]
-            y_ = gx - g[live]
-            sy = (s_ * y_).sum(1)
-            upd = (sy > 1e-12 * np.sqrt((s_ * s_).sum(1) * (y_ * y_).sum(1) + 1e-300)) & ~failed
-            li = live[upd]
-            S[:, li] = np.roll(S[:, li], -1, axis=0); Y[:, li] = np.roll(Y[:, li], -1, axis=0)
-            rho[:, li] = np.roll(rho[:, li], -1, axis=0)
-            S[-1, li] = s_[upd]; Y[-1, li] = y_[upd]; rho[-1, li] = 1.0 / sy[upd]
-            nhist[li] = np.minimum(nhist[li] + 1, self.m)
-            df = f[live] - fx
-            done = failed | ((df <= self.ftol * (1.0 + np.abs(fx))) & (np.abs(gx).max(1) <= self.gtol * (1.0 + np.abs(fx))))
-            done |= np.abs(gx).max(1) <= 1e-9
+                hdiag[sl] = hx
+            s_ = xnew - xl
+            y_ = gx - gl
+            sy = np.einsum("pd,pd->p", s_, y_)
+            yy = np.einsum("pd,pd->p", y_, y_)
+            upd = (sy > 1e-12 * np.sqrt(np.einsum("pd,pd->p", s_, s_) * yy + 1e-300)) & ~failed
+            slot = it % m
+            rho[slot] = 0.0
+            S[slot, sl] = s_; Y[slot, sl] = y_
+            rho[slot, sl] = np.where(upd, 1.0 / np.where(upd, sy, 1.0), 0.0)
+            gamma_all[sl] = np.where(upd, sy / np.maximum(yy, 1e-300), gamma)
+            nhist[sl] += upd
+            df = fl - fx
+            gmax = np.abs(gx).max(1)
+            done = failed | ((df <= self.ftol * (1.0 + np.abs(fx))) & (gmax <= self.gtol * (1.0 + np.abs(fx))))
+            done |= gmax <= 1e-9
             if self.prune is not None:
                 done |= self.prune(live, fx, df)
-            self.x[live] = xnew; f[live] = fx; g[live] = gx
-            self.iters[live] += 1
+            self.x[sl] = xnew; f[sl] = fx; g[sl] = gx
+            self.iters[sl] += 1
             converged[live[done]] = True
         self.f, self.g = f, g
         return self.x, f
