@@ -116,3 +116,27 @@ def test_stage1_analytic_and_finite_difference_gradients_agree():
     assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-3
     assert np.max(np.abs(a["lnl"] - b["lnl"])) < 1e-3
     assert np.max(np.abs(a["weights"] - b["weights"])) < 1e-4
+
+
+def test_stage1_on_the_bundled_locus_vs_restatement_and_phydesign():
+    """BASELINE config C1's data (chr1_918.nex, Euteleost.tree) through the GPU stage 1, site patterns and all: equal
+    to the independent restatement (1e-3) and within 6 % of the exchangeabilities PhyDesign published for this
+    locus (see tests/test_oracle_golden.py::test_stage1_restatement_against_phydesign_header)."""
+    engine = _engine()
+    import json
+    from oracle import stage1_oracle
+    from tapir_amd import compute, newick, nexus, pipeline
+    g = os.path.join(ROOT, "tests", "golden")
+    names, states = nexus.read_states(os.path.join(g, "chr1_918.nex"))
+    root = newick.read_tree(os.path.join(g, "Euteleost.tree"))
+    depth, factor = compute.correct_tree(root)
+    parent, blen, leaf = newick.to_arrays(root, names)
+    off = np.array([0, states.shape[1]])
+    pi = nexus.base_frequencies_from_histogram(engine.state_histogram(states, off))
+    got = pipeline.model_averaged_exchangeabilities(engine, states, off, pi, len(names), parent, blen, leaf, int(depth), [10],
+                                                    [[0, 10]], factor)
+    ref = stage1_oracle.model_averaged(states, parent, np.asarray(blen) / factor, leaf, pi[0])
+    assert np.max(np.abs(got[0] - ref["exch"]) / ref["exch"]) < 1e-3, (got, ref["exch"])
+    kat = json.load(open(os.path.join(g, "chr1_918_phydesign_rates.json")))
+    want = np.array([kat[k] for k in ("AC", "AG", "AT", "CG", "CT", "GT")])
+    assert np.max(np.abs(got[0] - want) / want) < 0.06

@@ -189,3 +189,29 @@ def test_oracle_rescaling_matches_log_space_sum(oracle):
     f, g, h = oracle.column_curve(st, parent, blen, np.array(leaf, dtype=np.int32), pi, exch, 0, np.array([1.0]))
     assert np.isfinite(f[0]) and f[0] < -700  # below log(DBL_MIN) ~ -708 only reachable with rescaling
     assert np.isfinite(g[0]) and np.isfinite(h[0])
+
+
+def test_stage1_restatement_against_phydesign_header(golden_dir):
+    """The only published stage-1 output the reference holds: the header of
+    tapir/tests/test-hyphy/chr1_918.subsmodel.phydesign.rates (2 decimals) gives the model-averaged
+    exchangeabilities PhyDesign's HyPhy run estimated for chr1_918.nex on Euteleost.tree: AC .96, AT .58, CG .36,
+    CT 1.87, GT .51.  The independent restatement (oracle/stage1_oracle.py: 203 models, Akaike weights with the
+    script's parameter counts) lands within 5 % of every one of them -- as close as a 226-column, 5-taxon likelihood
+    surface and HyPhy's 0.001 lnL optimisation precision allow; the general model alone (AC .88, AT .51, CG .20,
+    CT 1.86, GT .45) does not, so the file pins the AVERAGING, loosely."""
+    import json
+    from oracle import stage1_oracle
+    from tapir_amd import compute, newick, nexus
+    names, states = nexus.read_states(os.path.join(golden_dir, "chr1_918.nex"))
+    root = newick.read_tree(os.path.join(golden_dir, "Euteleost.tree"))
+    depth, factor = compute.correct_tree(root)
+    parent, blen, leaf = newick.to_arrays(root, names)
+    kat = json.load(open(os.path.join(golden_dir, "chr1_918_phydesign_rates.json")))
+    hist = np.bincount(np.where(states == 0, 15, states & 15).ravel(), minlength=16)[None, :16]
+    pi = nexus.base_frequencies_from_histogram(hist)[0]
+    assert np.max(np.abs(pi - np.array(kat["freqs_ACGT"]))) < 0.007          # the header rounds to 2 decimals
+    ref = stage1_oracle.model_averaged(states, parent, np.asarray(blen) / factor, leaf, pi)
+    want = np.array([kat[k] for k in ("AC", "AG", "AT", "CG", "CT", "GT")])
+    assert np.max(np.abs(ref["exch"] - want) / want) < 0.06, ref["exch"]
+    assert np.max(np.abs(ref["grm_exch"] - want) / want) > 0.3              # it is the averaging that matches
+    assert abs(sum(ref["weights"].values()) - 1.0) < 1e-12 and max(ref["weights"].values()) < 0.2
