@@ -337,6 +337,17 @@ def test_hyphy_protocol_shim(golden_dir, tmp_path, oracle):
     assert np.abs(got - ref["rate"])[ok].max() < 5.1e-5
     assert np.abs(np.array([r["ll"] for r in doc["sites"]["rates"]]) - ref["lnl"]).max() < 5.1e-5
     assert np.allclose(rates, got / factor)
+    # without the override the shim estimates the exchangeabilities itself, as HyPhy's script does (stage 1), and
+    # reports them in the JSON header (bf:1018-1031): within 6 % of PhyDesign's published values for this locus
+    env2 = {k: v for k, v in os.environ.items() if k != "TPHIP_EXCHANGEABILITIES"}
+    out2 = str(tmp_path / "chr1_918.stage1.rates")
+    p = subprocess.run([sys.executable, os.path.join(root, "bin", "tphip_hyphy"), "models_and_rates.bf"],
+                       input="\n".join([os.path.join(golden_dir, "chr1_918.nex"), tree, out2]), capture_output=True, text=True,
+                       env=env2, timeout=300)
+    assert p.returncode == 0 and not p.stdout.startswith("Error"), p.stdout[:500] + p.stderr[-500:]
+    sm = json.load(open(out2))["sites"]["subs_matrix"]
+    for key, want in (("AC", 0.96), ("AG", 1.0), ("AT", 0.58), ("CG", 0.36), ("CT", 1.87), ("GT", 0.51)):
+        assert abs(sm[key] - want) < 0.06 * want, sm
     # a missing alignment must surface as an "Error" on stdout, which tapir turns into "hyphy error: ..."
     p = subprocess.run([sys.executable, os.path.join(root, "bin", "tphip_hyphy"), "x.bf"], input="nope.nex\n%s\n%s" % (tree, out),
                        capture_output=True, text=True, env=env, timeout=300)
