@@ -7,6 +7,12 @@ Same positionals, same required/optional flags and defaults, same output directo
 `--multiprocessing` parallelises the host side only (NEXUS parsing, .rates files).  New, opt-in flags only: --device, --exchangeabilities / --subs-model,
 --integral-mode, --full-precision-rates.
 
+Several GPUs: launch it with `python -m torch.distributed.run --nproc-per-node G bin/tapir_compute.py ...` (one process
+per GPU).  The files are dealt round-robin over the ranks (what `Pool.map(worker, params)` did over cores,
+bin/tapir_compute.py:159-164); every rank writes the .rates files of its own loci into the one output directory
+rank 0 created; the per-locus PI rows are collected with a single all-gather (tapir_amd/dist.py: RCCL, or gloo
+without GPUs) and rank 0 writes the sqlite file in the original file order.
+
 Stage 1 of the HyPhy script (203-model fit + model averaging of the GTR exchangeabilities,
 models_and_rates.bf:405-897) runs on the GPU too (tapir_amd/stage1.py) unless the exchangeabilities are given
 with --exchangeabilities / --subs-model.
@@ -18,6 +24,7 @@ import sys
 import numpy as np
 
 from . import base, compute, db, newick, pipeline
+from . import dist as tdist
 
 
 def get_args(argv=None):
@@ -115,13 +122,43 @@ def read_subs_model(path, alignments):
     return np.array(exch), pis
 
 
+def _broadcast(obj, rank, world):
+    if world == 1:
+        return obj
+    import torch.distributed as dist
+    box = [obj if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def _gather_rows(tables, nfiles, rank, world, on_gpu):
+    """[n_local, W] rows of this rank's files (file i -> rank i mod world) -> [nfiles, W] in file order."""
+    if world == 1:
+        return tables
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(tables, dtype=np.float64))
+    if on_gpu:
+        t = t.cuda()
+    return tdist.gather_tables(t, nfiles, rank, world).cpu().numpy()
+
+
 def main(argv=None, engine_mod=None):
     """Main loop (mirrors bin/tapir_compute.py:125-177)."""
     args = get_args(argv)
-    print(welcome_message())
-    args.output = base.create_unique_dir(args.output)
-    # correct branch lengths
-    tree_depth, correction, tree = compute.correct_branch_lengths(args.tree, args.tree_format, d=args.output)
+    rank, world = tdist.rank_world()
+    on_gpu = engine_mod is None
+    if world > 1:
+        tdist.init_process_group(None if on_gpu else "gloo")
+        if on_gpu:
+            args.device = int(os.environ.get("LOCAL_RANK", rank))
+    if rank == 0:
+        print(welcome_message())
+        args.output = base.create_unique_dir(args.output)
+        # correct branch lengths
+        setup = (args.output,) + tuple(compute.correct_branch_lengths(args.tree, args.tree_format, d=args.output))
+    else:
+        setup = None
+    args.output, tree_depth, correction, tree = _broadcast(setup, rank, world)
     # generate a vector of times given start and stops
     T = int(tree_depth)
     subset_pi = dict()
@@ -134,38 +171,61 @@ def main(argv=None, engine_mod=None):
     workers = 1
     if args.multiprocessing:  # the reference: Pool(processes = cpu_count() - 1), bin/tapir_compute.py:162-163
         from multiprocessing import cpu_count
-        workers = max(1, min(16, cpu_count() - 1))  # forking hundreds of workers costs more than it saves
+        workers = max(1, min(16, (cpu_count() - 1) // world))  # forking hundreds of workers costs more than it saves
+    progress = pipeline.dot_progress if rank == 0 else None
+    W = T + len(args.times) + 2 * len(args.intervals)
     if not args.site_rates:
-        print("\nEstimating site rates and PI for files:")
-        alignments = base.get_files(args.alignments, '*.nex,*.nexus')
+        if rank == 0:
+            print("\nEstimating site rates and PI for files:")
+        files = base.get_files(args.alignments, '*.nex,*.nexus')
+        mine = [files[i] for i in tdist.shard_loci(len(files), rank, world)]
         exch, pi = None, None  # None: fit and model-average the exchangeabilities per locus (HyPhy stage 1)
         if args.exchangeabilities is not None:
             exch = np.array(args.exchangeabilities)
         if args.subs_model:
-            exch, pi = read_subs_model(args.subs_model, alignments)
-        pis, _ = pipeline.run_alignments(alignments, leaf_names, parent, blen, leaf, T, args.times, args.intervals,
-                                         correction, args.threshold, exch, pi=pi, subsets=subset_pi,
-                                         output_dir=args.output, device=args.device, integ_mode=integ_mode,
-                                         round_decimals=-1 if args.full_precision_rates else 4,
-                                         engine_mod=engine_mod, progress=pipeline.dot_progress, workers=workers)
+            exch, pi = read_subs_model(args.subs_model, mine)
+        if mine:
+            pis, out = pipeline.run_alignments(mine, leaf_names, parent, blen, leaf, T, args.times, args.intervals,
+                                               correction, args.threshold, exch, pi=pi, subsets=subset_pi,
+                                               output_dir=args.output, device=args.device, integ_mode=integ_mode,
+                                               round_decimals=-1 if args.full_precision_rates else 4,
+                                               engine_mod=engine_mod, progress=progress, workers=workers)
+            tables = out["final_tables"]
+        else:
+            pis, tables = [], np.zeros((0, W))
     else:
-        print("Estimating PI for files (--site-rate option):")
-        rate_files = base.get_files(args.alignments, '*.rates')
-        pis = pipeline.run_rate_files(rate_files, leaf_names, parent, blen, leaf, T, args.times, args.intervals,
-                                      correction, subsets=subset_pi, device=args.device, integ_mode=integ_mode,
-                                      engine_mod=engine_mod, progress=pipeline.dot_progress)
-    # store results somewhere
-    db_name = os.path.join(args.output, 'phylogenetic-informativeness.sqlite')
-    sys.stdout.write("\nStoring results in {0}...".format(db_name))
-    sys.stdout.flush()
-    conn, c = db.create_probe_db(db_name)
-    db.insert_pi_data(conn, c, pis)
-    conn.commit()
-    sys.stdout.write("DONE")
-    sys.stdout.flush()
-    print("\n")
-    c.close()
-    conn.close()
+        if rank == 0:
+            print("Estimating PI for files (--site-rate option):")
+        files = base.get_files(args.alignments, '*.rates')
+        mine = [files[i] for i in tdist.shard_loci(len(files), rank, world)]
+        if mine:
+            pis, tables = pipeline.run_rate_files(mine, leaf_names, parent, blen, leaf, T, args.times, args.intervals,
+                                                  correction, subsets=subset_pi, device=args.device, integ_mode=integ_mode,
+                                                  engine_mod=engine_mod, progress=progress, return_tables=True)
+        else:
+            pis, tables = [], np.zeros((0, W))
+    # the one collective: every rank's PI rows -> all rows in file order
+    all_tables = _gather_rows(tables, len(files), rank, world, on_gpu)
+    if rank == 0:
+        # store results somewhere
+        db_name = os.path.join(args.output, 'phylogenetic-informativeness.sqlite')
+        sys.stdout.write("\nStoring results in {0}...".format(db_name))
+        sys.stdout.flush()
+        conn, c = db.create_probe_db(db_name)
+        if world == 1:
+            db.insert_pi_data(conn, c, pis)
+        else:
+            db.insert_tables(conn, c, files, all_tables, T, args.times, args.intervals)
+        conn.commit()
+        sys.stdout.write("DONE")
+        sys.stdout.flush()
+        print("\n")
+        c.close()
+        conn.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return args.output
 
 

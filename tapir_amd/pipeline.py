@@ -181,11 +181,12 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
         tables = _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode)
     else:
         tables = out["tables"]
+    out["final_tables"] = tables   # [L, W] rows as stored in sqlite (after any subset slicing)
     return _tuples(alignments, per_locus, tables, T, times, intervals), out
 
 
 def run_rate_files(rate_files, leaf_names, parent, blen, leaf, T, times, intervals, correction, subsets=None,
-                   device=0, integ_mode=0, engine_mod=None, progress=None):
+                   device=0, integ_mode=0, engine_mod=None, progress=None, return_tables=False):
     """The --site-rates path (bin/tapir_compute.py:103-104, 153-158): re-read "rate" from each JSON, divide by
     the correction (again: the reference does not read `corrected_rates`), rewrite the file, NO culling."""
     from . import compute
@@ -203,7 +204,8 @@ def run_rate_files(rate_files, leaf_names, parent, blen, leaf, T, times, interva
         if progress:
             progress()
     tables = _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode)
-    return _tuples(rate_files, per_locus, tables, T, times, intervals)
+    tuples = _tuples(rate_files, per_locus, tables, T, times, intervals)
+    return (tuples, tables) if return_tables else tuples
 
 
 def _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode):

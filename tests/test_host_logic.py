@@ -490,3 +490,54 @@ def test_cli_default_runs_model_averaging(tmp_path):
     for m in mats:
         assert m["AG"] == 1.0 and all(m[k] > 0 for k in m)
     assert mats[0] != mats[1]  # per-locus estimates, not a shared constant
+
+
+_CLI_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import oracle_engine
+from tapir_amd import cli
+cli.main(%(argv)r, engine_mod=oracle_engine)
+'''
+
+
+def test_cli_two_ranks_gloo_matches_single_process(tmp_path):
+    """`torchrun --nproc-per-node 2 tapir_compute.py ...`: files dealt round-robin, each rank writes its own .rates
+    files into the one output directory, one all-gather of the PI rows, rank 0 writes sqlite in file order.
+    Everything on disk must equal the single-process run (5 files on 2 ranks: ragged shards)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    from tapir_amd import cli, synth
+    d = synth.simulate(5, 40, 5, 8)
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    tree = synth.write_nexus_dir(str(aln), d["states"].numpy(), d["locus_offsets"], d["names"], d["root"])
+    shutil.move(tree, tmp_path / "tree.newick")
+    outs = []
+    for name in ("single", "multi"):
+        out = tmp_path / name
+        out.mkdir()
+        outs.append(out)
+    argv = [str(aln), str(tmp_path / "tree.newick"), "--times", "10,30", "--intervals", "5-15,20-40",
+            "--exchangeabilities", "1,1.2,0.8,0.9,1.5,1", "--output"]
+    cli.main(argv + [str(outs[0])], engine_mod=oracle_engine)
+    script = tmp_path / "w.py"
+    script.write_text(_CLI_WORKER % {"root": ROOT, "argv": argv + [str(outs[1])]})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    names = sorted(os.listdir(outs[0]))
+    assert names == sorted(os.listdir(outs[1])) and len(names) == 7    # 5 .rates + tree + sqlite, ONE directory
+    for n in names:
+        if n.endswith(".rates") or n.endswith(".newick"):
+            assert open(outs[0] / n).read() == open(outs[1] / n).read(), n
+    for q in ("select l.locus, n.time, n.pi from loci l join net n on n.id = l.id order by l.id, n.time",
+              "select l.locus, n.time, n.pi from loci l join discrete n on n.id = l.id order by l.id, n.time",
+              "select l.locus, n.interval, n.pi, n.error from loci l join interval n on n.id = l.id order by l.id, n.interval",
+              "select sql from sqlite_master order by name"):
+        a = sqlite3.connect(outs[0] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
+        b = sqlite3.connect(outs[1] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
+        assert a == b and len(a) > 0
