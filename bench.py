@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--loci", type=int, default=None, help="override loci per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
+    ap.add_argument("--stage1-loci", type=int, default=4,
+                    help="also time HyPhy's stage 1 (model-averaged exchangeabilities) on the first N loci (0 = skip)")
     ap.add_argument("--integ-mode", type=int, default=0, help="0 = QUADPACK emulation (reference parity), 1 = closed form")
     args = ap.parse_args()
 
@@ -204,6 +206,8 @@ def main():
         "gen_seconds": t_gen,
     }
 
+    if rank == 0 and world == 1 and args.stage1_loci > 0:
+        out["stage1"] = stage1_sample(data, pin, min(args.stage1_loci, nloci), ncols, ntaxa, times, intervals)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(plan, data, pin, nloci, ncols, ntaxa, times, intervals, args, d_rate, d_nres)
     if rank == 0:
@@ -214,6 +218,27 @@ def main():
     plan.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def stage1_sample(data, pin, nl, ncols, ntaxa, times, intervals):
+    """Not part of `value`: wall time of the stage that precedes the per-site loop in HyPhy's script (203-model fit +
+    Akaike averaging of the exchangeabilities, models_and_rates.bf:405-897) on the first loci of the same batch, through
+    the product path (pattern compression, likelihood + gradient kernels, tapir_amd/stage1.py)."""
+    import time
+    import numpy as np
+    from tapir_amd import engine, nexus, pipeline
+    st = data["states"][:, :nl * ncols].cpu().numpy()
+    off = np.arange(nl + 1, dtype=np.int64) * ncols
+    t0 = time.perf_counter()
+    pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, off))
+    exch = pipeline.model_averaged_exchangeabilities(engine, st, off, pi, ntaxa, pin["parent"], pin["blen"], pin["leaf"],
+                                                     pin["T"], times, intervals, pin["correction"])
+    dt = time.perf_counter() - t0
+    true = np.asarray(data["exch"][:nl])
+    return {"loci": nl, "columns": nl * ncols, "seconds": dt, "columns_per_s": nl * ncols / dt,
+            "note": "host-pointer path incl. copies; estimates vs generating rates differ by design (the simulation has "
+                    "Gamma site rates, stage 1 assumes one rate)",
+            "max_rel_dev_from_generating_rates": float(np.max(np.abs(exch - true / true[:, 1:2]) / (true / true[:, 1:2])))}
 
 
 def cpu_baseline(plan, data, pin, nloci, ncols, ntaxa, times, intervals, args, d_rate, d_nres):
