@@ -24,6 +24,7 @@
 namespace tphip {
 
 constexpr int kLikBlock = 128;
+constexpr double kLikTiny = 1e-300;   // floor of a tip message entry (see the tip arm of the kernels)
 
 struct LikParams {
     const uint8_t* states;         // [ntaxa][ncols_total]
@@ -196,9 +197,11 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
                 double z[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) z[k] = et[k] * tipY[m * 4 + k];
+                // a message entry is a probability: for a near-zero branch the eigen-sum cancels to rounding noise around 0,
+                // which must not turn the partial negative
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[i] *= fma(U[i * 4 + 3], z[3], fma(U[i * 4 + 2], z[2], fma(U[i * 4 + 1], z[1], U[i * 4] * z[0])));
+                    acc[i] *= fmax(fma(U[i * 4 + 3], z[3], fma(U[i * 4 + 2], z[2], fma(U[i * 4 + 1], z[1], U[i * 4] * z[0]))), kLikTiny);
             } else if (op.x == OP_BRANCH) {
                 const double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
                 if (mx < 1e-200 && mx > 0) {   // rescale (deep trees); rare, lane-divergent is fine here
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
                     for (int k = 0; k < 4; ++k) z[k] = ef[k] * tipY[m * 4 + k];
                     mulU(z, v);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] *= v[i];
+                    for (int i = 0; i < 4; ++i) acc[i] *= fmax(v[i], kLikTiny);
                 } else if (op.x == OP_BRANCH) {
                     double* slot = tape + (size_t)op.w * 4 * kGradBlock;
 #pragma unroll
@@ -488,6 +491,7 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
                     mulU(z, v);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        v[i] = fmax(v[i], kLikTiny);
                         acc[i] *= lik_rcp(v[i]);    // the partial before this tip was folded in
                         vb[i] = ab[i] * acc[i];     // adjoint of the tip's message
                         ab[i] *= v[i];

@@ -25,8 +25,11 @@ Parity: HyPhy's own optimiser and its results for this stage are pinned by no fi
 import numpy as np
 
 RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
-LOG_RATE_MIN, LOG_RATE_MAX = -12.0, 12.0    # exchangeabilities within [6e-6, 1.6e5] (HyPhy: [0, 10000])
-LOG_BLEN_MIN, LOG_BLEN_MAX = -30.0, 4.0     # branch lengths within [1e-13, 55]
+# Bounds (HyPhy: rates in [0, 10000], lengths >= 0).  The lower ones keep every transition probability
+# q_ij * t >= ~1e-15 above the rounding noise (~2e-16) of its eigen-sum; below them a rate or a length is zero for
+# every purpose of this stage.
+LOG_RATE_MIN, LOG_RATE_MAX = -7.0, 9.2      # exchangeabilities within [9e-4, 1e4]
+LOG_BLEN_MIN, LOG_BLEN_MAX = -23.0, 4.0     # branch lengths within [1e-10, 55]
 MAX_LOG_STEP = 2.0                          # largest move of a log-parameter in one iteration
 PRUNE_NATS = 30.0                           # see Stage1.fit_submodels
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T

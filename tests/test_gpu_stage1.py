@@ -140,3 +140,38 @@ def test_stage1_on_the_bundled_locus_vs_restatement_and_phydesign():
     kat = json.load(open(os.path.join(g, "chr1_918_phydesign_rates.json")))
     want = np.array([kat[k] for k in ("AC", "AG", "AT", "CG", "CT", "GT")])
     assert np.max(np.abs(got[0] - want) / want) < 0.06
+
+
+def test_stage1_degenerate_loci_stay_finite():
+    """Edge cases of the domain: an empty locus, a locus of gaps only, an invariant locus (nothing to estimate: every
+    model fits equally, lengths collapse to the lower bound), one informative locus among them, and a 2-taxon tree.
+    Nothing may turn NaN/inf; AG stays 1; weights sum to 1; the flat loci average to the e^-k prior over models."""
+    engine = _engine()
+    from tapir_amd import pipeline, stage1, synth, newick
+    d = synth.simulate(1, 300, 6, 3)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    good = d["states"].numpy()
+    gaps = np.full((6, 50), 15, np.uint8)
+    same = np.tile(np.array([[1], [1], [1], [1], [1], [1]], np.uint8), (1, 80))
+    st = np.concatenate([gaps, same, good], axis=1)
+    off = np.array([0, 0, 50, 130, 430])     # empty, gaps, invariant, informative
+    pi = np.tile(np.array([0.25, 0.25, 0.25, 0.25]), (4, 1))
+    pi[3] = np.asarray(d["pi"][0])
+    exch = pipeline.model_averaged_exchangeabilities(engine, st, off, pi, 6, pin["parent"], pin["blen"], pin["leaf"], pin["T"],
+                                                     [1], [[0, 1]], pin["correction"])
+    assert exch.shape == (4, 6) and np.all(np.isfinite(exch)) and np.all(exch[:, 1] == 1.0)
+    assert np.all(exch > 5e-4) and np.all(exch < 2e4)
+    assert np.allclose(exch[0], 1.0) and np.allclose(exch[1], 1.0)      # no data: every rate stays at its start
+    # the informative locus is unaffected by its degenerate neighbours
+    alone = pipeline.model_averaged_exchangeabilities(engine, good, np.array([0, 300]), pi[3:], 6, pin["parent"], pin["blen"],
+                                                      pin["leaf"], pin["T"], [1], [[0, 1]], pin["correction"])
+    assert np.max(np.abs(alone[0] - exch[3]) / exch[3]) < 1e-6
+    # two taxa
+    root = newick.parse("(a:10,b:20);")
+    parent, blen, leaf = newick.to_arrays(root, ["a", "b"])
+    rng = np.random.default_rng(1)
+    two = (1 << rng.integers(0, 4, size=(2, 400))).astype(np.uint8)
+    two[1, :300] = two[0, :300]
+    e2 = pipeline.model_averaged_exchangeabilities(engine, two, np.array([0, 400]), np.full((1, 4), 0.25), 2, parent, blen, leaf,
+                                                   30, [1], [[0, 1]], 1.0)
+    assert np.all(np.isfinite(e2)) and e2[0, 1] == 1.0
