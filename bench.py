@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
     ap.add_argument("--stage1-loci", type=int, default=4,
                     help="also time HyPhy's stage 1 (model-averaged exchangeabilities) on the first N loci (0 = skip)")
+    ap.add_argument("--gamma-categories", type=int, default=1,
+                    help="K > 1: opt-in discrete-gamma rate mixture in the site-rate stage (alpha 0.5); not the headline config")
     ap.add_argument("--integ-mode", type=int, default=0, help="0 = QUADPACK emulation (reference parity), 1 = closed form")
     args = ap.parse_args()
 
@@ -90,7 +92,9 @@ def main():
 
     plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], data["locus_offsets"], data["pi"], data["exch"],
                        pin["T"], times, intervals, correction=pin["correction"], threshold=3, round_decimals=4,
-                       integ_mode=args.integ_mode, device=local_rank)
+                       integ_mode=args.integ_mode, device=local_rank,
+                       **({} if args.gamma_categories <= 1 else
+                          dict(zip(("cat_rates", "cat_weights"), __import__("tapir_amd.compute", fromlist=["x"]).discrete_gamma(0.5, args.gamma_categories)))))
     n = plan.ncols
     W = plan.width
     d_states = data["states"]
@@ -181,8 +185,9 @@ def main():
         "data": "synthetic (seeded Yule tree, GTR-simulated columns, Gamma(0.5) site rates, 5% gaps; SURVEY.md 8d)",
         "config": {
             "workload": "%s shape per GPU: %d loci x %d columns x %d taxa, per-site GTR rate ML + PI "
-                        "(T=%d net times, %d --times, %d --intervals, integ_mode=%d)"
-                        % (args.workload, nloci, ncols, ntaxa, pin["T"], len(times), len(intervals), args.integ_mode),
+                        "(T=%d net times, %d --times, %d --intervals, integ_mode=%d)%s"
+                        % (args.workload, nloci, ncols, ntaxa, pin["T"], len(times), len(intervals), args.integ_mode,
+                           "" if args.gamma_categories <= 1 else ", +G mixture of %d rate categories (extension)" % args.gamma_categories),
             "columns_per_gpu": n,
             "loci_per_gpu": nloci,
             "parallelism": "loci sharded over %d rank(s), one all-gather of PI tables" % world,

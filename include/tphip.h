@@ -101,6 +101,12 @@ typedef struct tphip_plan_desc {
     int32_t threshold;         /* columns with fewer A/C/G/T cells become NaN (compute.py:96-110)      */
     int32_t round_decimals;    /* 4 = round rates as HyPhy's Format(x,0,4) does before PI (bf:1093-1095);
                                   < 0 = keep full precision                                            */
+    /* Opt-in extension, NOT in the reference (its script has no rate mixture): a discrete mixture of
+     * rate categories on top of the per-site rate, L(s) = sum_k cat_weight[k] L(s * cat_rate[k]) -- the "+G" of
+     * GTR+G when the categories are the discrete gamma of Yang (1994).  ncat <= 1 = the reference's model. */
+    int32_t ncat;              /* number of categories, at most 16                                    */
+    const double *cat_rate;    /* [ncat] rate multipliers > 0 (mean 1 keeps `rate` = kappa * s interpretable) */
+    const double *cat_weight;  /* [ncat] weights > 0 (normalised by the library)                       */
 } tphip_plan_desc;
 
 int tphip_plan_create(const tphip_plan_desc *desc, tphip_plan **out);

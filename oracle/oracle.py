@@ -260,8 +260,9 @@ def correct_branch_lengths_values(newick_text):
 # ctypes wrappers over tapir_oracle.c
 # --------------------------------------------------------------------------------------------------
 
-def site_rates(states, parent, blen, leaf_taxon, pi, exch):
+def site_rates(states, parent, blen, leaf_taxon, pi, exch, cat_rates=None, cat_weights=None):
     """HyPhy stage 2 restatement for one locus. states: uint8 [ntaxa, ncols] masks.
+    cat_rates / cat_weights: optional discrete rate mixture on top of the site rate (not in the reference).
     Returns dict(rate, subst, lnl, flag, nres, nevals)."""
     states = np.ascontiguousarray(states, dtype=np.uint8)
     ntaxa, ncols = states.shape
@@ -272,6 +273,16 @@ def site_rates(states, parent, blen, leaf_taxon, pi, exch):
     exch = np.ascontiguousarray(exch, dtype=np.float64)
     rate = np.empty(ncols); subst = np.empty(ncols); lnl = np.empty(ncols)
     flag = np.empty(ncols, dtype=np.uint8); nres = np.empty(ncols, dtype=np.int32)
+    if cat_rates is not None and len(cat_rates) > 1:
+        cr = np.ascontiguousarray(cat_rates, dtype=np.float64)
+        cw = np.ascontiguousarray(cat_weights if cat_weights is not None else np.full(len(cr), 1.0 / len(cr)), dtype=np.float64)
+        fn = lib().orc_site_rates_mix
+        fn.restype = ctypes.c_int64
+        ne = fn(states.ctypes.data_as(_c_u8p), ctypes.c_int64(ncols), ctypes.c_int32(ntaxa), ctypes.c_int32(len(parent)),
+                parent.ctypes.data_as(_c_i32p), _dp(blen), leaf_taxon.ctypes.data_as(_c_i32p), _dp(pi), _dp(exch),
+                ctypes.c_int32(len(cr)), _dp(cr), _dp(cw), _dp(rate), _dp(subst), _dp(lnl),
+                flag.ctypes.data_as(_c_u8p), nres.ctypes.data_as(_c_i32p))
+        return dict(rate=rate, subst=subst, lnl=lnl, flag=flag, nres=nres, nevals=int(ne))
     ne = lib().orc_site_rates(states.ctypes.data_as(_c_u8p), ncols, ntaxa, len(parent),
                               parent.ctypes.data_as(_c_i32p), _dp(blen), leaf_taxon.ctypes.data_as(_c_i32p),
                               _dp(pi), _dp(exch), _dp(rate), _dp(subst), _dp(lnl),

@@ -467,7 +467,10 @@ void orc_net_integrals(const double *rates, int64_t n, const int32_t *intervals,
  * S = D^{1/2} Q D^{-1/2}, D = diag(pi); Jacobi-rotate S = V L V^T; then exp(Qt) = U exp(Lt) U^-1 with
  * U = D^{-1/2} V, U^-1 = V^T D^{1/2}.
  * ---------------------------------------------------------------------------------------------- */
-typedef struct { double lam[4], U[4][4], Ui[4][4], pi[4], kappa; } orc_model;
+#define ORC_MAX_CAT 16
+/* ncat > 1: discrete mixture of rate categories on top of the per-site rate (the "+G" of GTR+G; NOT in the reference's
+ * script): L(s) = sum_k w_k L(s * rho_k).  ncat <= 1: the reference's model. */
+typedef struct { double lam[4], U[4][4], Ui[4][4], pi[4], kappa; int ncat; double cat_rate[ORC_MAX_CAT], cat_logw[ORC_MAX_CAT]; } orc_model;
 
 static void jacobi4(double A[4][4], double V[4][4], double w[4]) {
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = (i == j);
@@ -511,6 +514,7 @@ static void build_model(const double pi[4], const double exch[6], orc_model *m) 
         m->pi[i] = pi[i];
         sq[i] = sqrt(pi[i]);
     }
+    m->ncat = 0;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) S[i][j] = sq[i] * Q[i][j] / sq[j];
     for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) S[i][j] = S[j][i] = 0.5 * (S[i][j] + S[j][i]);
     jacobi4(S, V, m->lam);
@@ -541,8 +545,8 @@ typedef struct {
 
 /* log L(s) and derivatives wrt u = log s for one column (pruning, bf:1053 evaluates this through
  * LikelihoodFunction siteLikelihood = (siteFilter, siteTree)). */
-static void column_loglik(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols,
-                          int64_t col, double u, double *f, double *g, double *h) {
+static void column_loglik_one(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols,
+                              int64_t col, double u, double *f, double *g, double *h) {
     double s = exp(u);
     double(*X)[3][4] = (double(*)[3][4])tr->part;
     int scale = 0;
@@ -591,6 +595,28 @@ static void column_loglik(const orc_model *m, const orc_tree *tr, const uint8_t 
     *f = log(L) + scale * 0.6931471805599453;
     *g = s * gs;
     *h = s * s * hs + s * gs;
+}
+
+/* The objective the optimiser sees: one category, or the mixture sum_k w_k L(s rho_k).  With f_k, g_k, h_k the
+ * log-likelihood and its u-derivatives of category k at u + log rho_k, and p_k its posterior weight:
+ * f = logsumexp(log w_k + f_k), g = sum p_k g_k, h = sum p_k (h_k + g_k^2) - g^2. */
+static void column_loglik(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols,
+                          int64_t col, double u, double *f, double *g, double *h) {
+    if (m->ncat <= 1) { column_loglik_one(m, tr, states, ncols, col, u, f, g, h); return; }
+    double fk[ORC_MAX_CAT], gk[ORC_MAX_CAT], hk[ORC_MAX_CAT], top = -INFINITY;
+    for (int k = 0; k < m->ncat; ++k) {
+        column_loglik_one(m, tr, states, ncols, col, u + log(m->cat_rate[k]), &fk[k], &gk[k], &hk[k]);
+        fk[k] += m->cat_logw[k];
+        if (fk[k] > top) top = fk[k];
+    }
+    double z = 0, a = 0, b = 0;
+    for (int k = 0; k < m->ncat; ++k) {
+        const double p = exp(fk[k] - top);
+        z += p; a += p * gk[k]; b += p * (hk[k] + gk[k] * gk[k]);
+    }
+    *f = top + log(z);
+    *g = a / z;
+    *h = b / z - (*g) * (*g);
 }
 
 /* Safeguarded Newton on u = log s from u = 0, to the local maximum uphill of the start. */
@@ -657,14 +683,19 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
 
 /* One locus.  Outputs per column: rate = kappa*s (bf:1061), subst = rate*chronoLength (bf:1056-1060),
  * lnl, flag, nres = number of plain A/C/G/T cells (tapir/compute.py:104). Returns total evaluations. */
-int64_t orc_site_rates(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
-                       const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
-                       double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
+int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                           const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
+                           int32_t ncat, const double *cat_rate, const double *cat_weight,
+                           double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
     orc_model m;
     orc_tree tr = {nnodes, ntaxa, parent, leaf_taxon, blen, NULL};
     int64_t total_eval = 0;
     double chrono = 0.0;
     build_model(pi, exch, &m);
+    if (ncat > 1 && ncat <= ORC_MAX_CAT) {
+        m.ncat = ncat;
+        for (int k = 0; k < ncat; ++k) { m.cat_rate[k] = cat_rate[k]; m.cat_logw[k] = log(cat_weight[k]); }
+    }
     for (int n = 0; n < nnodes; ++n) if (parent[n] >= 0) chrono += blen[n]; /* bf:1006-1013 */
     tr.part = (double *)malloc(sizeof(double) * 12 * (size_t)nnodes);
     for (int64_t c = 0; c < ncols; ++c) {
@@ -697,6 +728,13 @@ int64_t orc_site_rates(const uint8_t *states, int64_t ncols, int32_t ntaxa, int3
     }
     free(tr.part);
     return total_eval;
+}
+
+int64_t orc_site_rates(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                       const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
+                       double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
+    return orc_site_rates_mix(states, ncols, ntaxa, nnodes, parent, blen, leaf_taxon, pi, exch, 0, NULL, NULL, rate, subst, lnl,
+                              flag, nres_out);
 }
 
 /* log-likelihood curve of one column at given u values (used by tests to check derivatives) */

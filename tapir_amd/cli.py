@@ -5,7 +5,7 @@ Same positionals, same required/optional flags and defaults, same output directo
 (Tree_<factor>_<depth>.newick, <alignment>.rates JSON per locus, phylogenetic-informativeness.sqlite).
 `--hyphy` and `--template` are accepted for compatibility and ignored (there is no subprocess);
 `--multiprocessing` parallelises the host side only (NEXUS parsing, .rates files).  New, opt-in flags only: --device, --exchangeabilities / --subs-model,
---integral-mode, --full-precision-rates.
+--integral-mode, --full-precision-rates, --gamma-categories / --gamma-alpha.
 
 Several GPUs: launch it with `python -m torch.distributed.run --nproc-per-node G bin/tapir_compute.py ...` (one process
 per GPU).  The files are dealt round-robin over the ranks (what `Pool.map(worker, params)` did over cores,
@@ -66,6 +66,10 @@ def get_args(argv=None):
                      help="tab-delimited file: alignment file name, AC, AG, AT, CG, CT, GT [, A, C, G, T frequencies]")
     new.add_argument('--integral-mode', choices=['quadpack', 'closed'], default='quadpack',
                      help="quadpack = emulate scipy.integrate.quad incl. its error column; closed = analytic")
+    new.add_argument('--gamma-categories', type=int, default=1,
+                     help="K > 1: discrete-gamma mixture of K rate categories on top of each site's rate (GTR+G; the "
+                          "reference's HyPhy script has none, so K = 1 is the drop-in setting)")
+    new.add_argument('--gamma-alpha', type=float, default=0.5, help="shape of that gamma distribution")
     new.add_argument('--full-precision-rates', action='store_true',
                      help="do not round site rates to 4 decimals before PI (the reference rounds through its JSON file)")
     return parser.parse_args(argv)
@@ -173,6 +177,8 @@ def main(argv=None, engine_mod=None):
         from multiprocessing import cpu_count
         workers = max(1, min(16, (cpu_count() - 1) // world))  # forking hundreds of workers costs more than it saves
     progress = pipeline.dot_progress if rank == 0 else None
+    cat_rates, cat_weights = (compute.discrete_gamma(args.gamma_alpha, args.gamma_categories)
+                              if args.gamma_categories > 1 else (None, None))
     W = T + len(args.times) + 2 * len(args.intervals)
     if not args.site_rates:
         if rank == 0:
@@ -189,7 +195,8 @@ def main(argv=None, engine_mod=None):
                                                correction, args.threshold, exch, pi=pi, subsets=subset_pi,
                                                output_dir=args.output, device=args.device, integ_mode=integ_mode,
                                                round_decimals=-1 if args.full_precision_rates else 4,
-                                               engine_mod=engine_mod, progress=progress, workers=workers)
+                                               engine_mod=engine_mod, progress=progress, workers=workers,
+                                               cat_rates=cat_rates, cat_weights=cat_weights)
             tables = out["final_tables"]
         else:
             pis, tables = [], np.zeros((0, W))

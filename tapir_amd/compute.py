@@ -125,3 +125,20 @@ def get_informative_sites(alignment, threshold=4):
 def cull_uninformative_rates(rates, inform):
     """NaN-out rates of uninformative sites (tapir/compute.py:108-110)."""
     return rates * inform
+
+
+def discrete_gamma(alpha, ncat):
+    """Yang's (1994) discrete gamma: `ncat` equiprobable categories of a Gamma(alpha, alpha) rate distribution (mean 1),
+    each represented by its mean.  Returns (rates[ncat], weights[ncat]).  Host-side helper for the opt-in rate mixture
+    of the site-rate stage (tphip_plan_desc.ncat); the reference's script has no such mixture."""
+    from scipy.special import gammainc, gammaincinv
+    ncat = int(ncat)
+    if ncat <= 1:
+        return np.ones(1), np.ones(1)
+    if not alpha > 0:
+        raise ValueError("alpha must be positive")
+    cuts = gammaincinv(alpha, np.arange(1, ncat) / ncat)          # category boundaries of Gamma(alpha, 1)
+    upper = np.concatenate([gammainc(alpha + 1.0, cuts), [1.0]])
+    lower = np.concatenate([[0.0], gammainc(alpha + 1.0, cuts)])
+    rates = ncat * (upper - lower)                                # E[X / alpha | category] with X ~ Gamma(alpha, 1)
+    return rates, np.full(ncat, 1.0 / ncat)

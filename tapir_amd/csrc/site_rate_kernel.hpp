@@ -65,6 +65,8 @@ struct SiteParams {
     const int64_t* work_prefix;    // [nloci+1] exclusive scan of work_count (scan_counts_kernel)
     int64_t nloci;
     int32_t persistent;            // 1: grid = resident waves, equal shares of the global work list; 0: grid = slices
+    int32_t ncat;                  // > 1: discrete rate mixture on top of the site rate (tphip_plan_desc.ncat)
+    const double* cat;             // [2 * ncat]: category rate multipliers, then log weights
     double* rate;
     double* subst;
     double* lnl;
@@ -345,6 +347,37 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
     f = log(L) + (double)scale * 0.6931471805599453;
 }
 
+// The objective the optimiser sees.  ncat <= 1 (the reference's model): one evaluation at s.  ncat > 1: the mixture
+// L(s) = sum_k w_k L(s rho_k) -- the "+G" of GTR+G as an opt-in extension the reference's script does not have
+// (SURVEY F2).  With f_k, g_k, h_k the category's log-likelihood and u-derivatives and p_k its posterior weight:
+// f = logsumexp(log w_k + f_k), g = sum p_k g_k, h = sum p_k (h_k + g_k^2) - g^2 (running maximum, one pass).
+template <int NW>
+__device__ __forceinline__ void evaluate_site(const SiteParams& P, const ModelRegs& R, const double* __restrict__ wtab,
+                                              const double* __restrict__ etab, double* __restrict__ stack, int64_t col,
+                                              const uint32_t (&pk)[NW > 0 ? NW : 1], double s, double& f, double& g,
+                                              double& h) {
+    const int K = P.ncat > 1 ? P.ncat : 1;
+    double top = -INFINITY, z = 0.0, a = 0.0, b = 0.0;
+    for (int k = 0; k < K; ++k) {
+        double fk, gk, hk;
+        evaluate_column<NW>(P, R, wtab, etab, stack, col, pk, P.ncat > 1 ? s * P.cat[k] : s, fk, gk, hk);
+        if (P.ncat <= 1) { f = fk; g = gk; h = hk; return; }
+        fk += P.cat[K + k];
+        if (fk > top) {
+            const double r = exp(top - fk);   // exp(-inf) = 0 on the first category
+            z *= r; a *= r; b *= r;
+            top = fk;
+        }
+        const double p = exp(fk - top);
+        z += p;
+        a = fma(p, gk, a);
+        b = fma(p, fma(gk, gk, hk), b);
+    }
+    f = top + log(z);
+    g = a / z;
+    h = b / z - g * g;
+}
+
 // tip table: wtab[mask][k] = sum_{j in mask} U^-1[k][j]   (row 0 of U^-1 is pi)
 __device__ __forceinline__ void build_tip_table(const LocusModel* __restrict__ M, double* wtab, int lane) {
     int mask = lane >> 2, k = lane & 3;
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         int it = 0;
         while (true) {
             double f, g, h;
-            evaluate_column<NW>(P, R, wtab, etab, stack, col, pk, exp(u), f, g, h);
+            evaluate_site<NW>(P, R, wtab, etab, stack, col, pk, exp(u), f, g, h);
             if (!done) {
                 ++evals;
                 ++it;
@@ -573,7 +606,7 @@ __global__ __launch_bounds__(kSiteBlock) void eval_columns_kernel(EvalParams E) 
         const int64_t col = active ? want : first;
         double f, g, h;
         const uint32_t none[1] = {0};
-        evaluate_column<0>(P, R, wtab, etab, stack, col, none, exp(E.u[col]), f, g, h);
+        evaluate_site<0>(P, R, wtab, etab, stack, col, none, exp(E.u[col]), f, g, h);
         if (active) { E.f[col] = f; E.g[col] = g; E.h[col] = h; }
     }
 }

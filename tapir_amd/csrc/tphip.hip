@@ -88,6 +88,8 @@ struct tphip_plan {
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
     DevBuf<int32_t> d_tip_taxon, d_op_node;
+    int32_t ncat = 0;
+    DevBuf<double> d_cat;     // [2 * ncat] category rates, then log weights
     DevBuf<int4> d_lik_ops;   // {code, taxon, node, tape slot} per op for the locus likelihood / gradient kernels
     double* d_tape = nullptr;   // reverse-mode tape of locus_grad_kernel, grown on demand
     size_t tape_bytes = 0;
@@ -137,6 +139,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
     plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
     plan->d_lik_ops.release();
+    plan->d_cat.release();
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
@@ -177,11 +180,25 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     }
     const int64_t ncols = d->locus_offsets[d->nloci];
     if (ncols >= (int64_t)1 << 31) return fail(TPHIP_ERR_INVALID, "more than 2^31-1 columns in one batch");
+    std::vector<double> cat;
+    if (d->ncat > 1) {
+        if (d->ncat > 16) return fail(TPHIP_ERR_INVALID, "at most 16 rate categories");
+        if (!d->cat_rate || !d->cat_weight) return fail(TPHIP_ERR_INVALID, "rate categories need cat_rate and cat_weight");
+        double wsum = 0;
+        for (int k = 0; k < d->ncat; ++k) {
+            if (!(d->cat_rate[k] > 0.0) || !(d->cat_weight[k] > 0.0) || !std::isfinite(d->cat_rate[k]) || !std::isfinite(d->cat_weight[k]))
+                return fail(TPHIP_ERR_INVALID, "category rates and weights must be positive and finite");
+            wsum += d->cat_weight[k];
+        }
+        cat.resize(2 * (size_t)d->ncat);
+        for (int k = 0; k < d->ncat; ++k) { cat[k] = d->cat_rate[k]; cat[d->ncat + k] = std::log(d->cat_weight[k] / wsum); }
+    }
 
     tphip_plan* p = new tphip_plan();
     p->device = d->device; p->ntaxa = d->ntaxa; p->nloci = d->nloci; p->ncols = ncols;
     p->T = d->T; p->n_t = d->n_t; p->n_i = d->n_i; p->integ_mode = d->integ_mode;
     p->threshold = d->threshold; p->round_decimals = d->round_decimals; p->correction = d->correction;
+    p->ncat = cat.empty() ? 0 : d->ncat;
     std::string terr = build_tree_program(d->ntaxa, d->nnodes, d->parent, d->branch_len, d->leaf_taxon, &p->prog);
     if (!terr.empty()) { delete p; return fail(TPHIP_ERR_INVALID, "tree: " + terr); }
     if (p->prog.nleaves != d->ntaxa) {  // HyPhy refuses a tree / alignment mismatch as well
@@ -227,6 +244,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->nwords = (int32_t)((tip_taxon.size() + 7) / 8);
     if (e == hipSuccess) e = p->d_tip_taxon.upload(tip_taxon);
     if (e == hipSuccess) e = p->d_op_node.upload(p->prog.op_node);
+    if (e == hipSuccess && !cat.empty()) e = p->d_cat.upload(cat);
     if (e == hipSuccess) {
         std::vector<int4> lops(p->prog.ops.size());
         for (size_t i = 0; i < lops.size(); ++i) {
@@ -405,6 +423,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     if (p->n_site_chunks > 0) {
         const dim3 grid((unsigned)(p->site_persistent ? p->site_waves : p->n_site_chunks)), block(kSiteBlock);
         S.persistent = p->site_persistent;
+        S.ncat = p->ncat; S.cat = p->d_cat.p;
         // register-resident tip states for up to 256 tips; beyond that the byte path (NW = 0)
         const char* fb = getenv("TPHIP_FORCE_BYTE_PATH");  // test/tuning knob: exercise the NW = 0 kernel on any tree
         if (fb && fb[0] == '1') site_rate_kernel<0><<<grid, block, lds, st>>>(S);
@@ -806,7 +825,7 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
     E.S.chunk_cols = p->site_chunk_cols;
     E.S.packed = nullptr; E.S.nwords = 0;
-    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
+    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
     E.S.flag = nullptr; E.S.eval_counter = nullptr;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);

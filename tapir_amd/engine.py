@@ -28,7 +28,8 @@ class PlanDesc(ctypes.Structure):
     _fields_ = [("device", _i32), ("ntaxa", _i32), ("nnodes", _i32), ("parent", _vp), ("branch_len", _vp),
                 ("leaf_taxon", _vp), ("nloci", _i64), ("locus_offsets", _vp), ("pi", _vp), ("exch", _vp),
                 ("T", _i32), ("times", _vp), ("n_t", _i32), ("intervals", _vp), ("n_i", _i32),
-                ("integ_mode", _i32), ("correction", _f64), ("threshold", _i32), ("round_decimals", _i32)]
+                ("integ_mode", _i32), ("correction", _f64), ("threshold", _i32), ("round_decimals", _i32),
+                ("ncat", _i32), ("cat_rate", _vp), ("cat_weight", _vp)]
 
 
 # every symbol include/tphip.h declares: (name, restype, argtypes)
@@ -120,7 +121,8 @@ class Plan:
     """
 
     def __init__(self, ntaxa, parent, branch_len, leaf_taxon, locus_offsets, pi, exch, T, times, intervals,
-                 correction=1.0, threshold=3, round_decimals=4, integ_mode=INTEG_QUADPACK, device=0):
+                 correction=1.0, threshold=3, round_decimals=4, integ_mode=INTEG_QUADPACK, device=0, cat_rates=None,
+                 cat_weights=None):
         lib = load()
         self._lib = lib
         self._h = _vp()
@@ -129,6 +131,12 @@ class Plan:
                           pi=_np(pi, np.float64).reshape(-1), exch=_np(exch, np.float64).reshape(-1),
                           times=_np(times, np.int32).reshape(-1), iv=_np(intervals, np.int32).reshape(-1))
         k = self._keep
+        ncat = 0 if cat_rates is None else len(cat_rates)
+        if ncat > 1:   # opt-in rate mixture on top of the site rate (not in the reference; see include/tphip.h)
+            k["cr"] = _np(cat_rates, np.float64).reshape(-1)
+            k["cw"] = _np(np.full(ncat, 1.0 / ncat) if cat_weights is None else cat_weights, np.float64).reshape(-1)
+            if k["cw"].size != ncat:
+                raise TphipError("cat_weights must match cat_rates")
         self.nloci = len(k["off"]) - 1
         if k["pi"].size != 4 * self.nloci or k["exch"].size != 6 * self.nloci:
             raise TphipError("pi must be [L,4] and exch [L,6] for L = len(locus_offsets) - 1")
@@ -139,7 +147,9 @@ class Plan:
                      locus_offsets=k["off"].ctypes.data, pi=k["pi"].ctypes.data, exch=k["exch"].ctypes.data, T=int(T),
                      times=k["times"].ctypes.data, n_t=k["times"].size, intervals=k["iv"].ctypes.data,
                      n_i=k["iv"].size // 2, integ_mode=integ_mode, correction=float(correction),
-                     threshold=int(threshold), round_decimals=int(round_decimals))
+                     threshold=int(threshold), round_decimals=int(round_decimals),
+                     ncat=ncat if ncat > 1 else 0, cat_rate=k["cr"].ctypes.data if ncat > 1 else None,
+                     cat_weight=k["cw"].ctypes.data if ncat > 1 else None)
         _check(lib.tphip_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
         self.device = device
         self.ntaxa = ntaxa

@@ -30,7 +30,8 @@ def compress_columns(states, locus_offsets, device=0, want_map=True):
 
 class Plan:
     def __init__(self, ntaxa, parent, branch_len, leaf_taxon, locus_offsets, pi, exch, T, times, intervals,
-                 correction=1.0, threshold=3, round_decimals=4, integ_mode=0, device=0):
+                 correction=1.0, threshold=3, round_decimals=4, integ_mode=0, device=0, cat_rates=None, cat_weights=None):
+        self.cat_rates, self.cat_weights = cat_rates, cat_weights
         self.ntaxa = ntaxa
         self.parent = np.asarray(parent, np.int32)
         self.blen = np.asarray(branch_len, np.float64)
@@ -88,7 +89,7 @@ class Plan:
             sl = slice(self.off[l], self.off[l + 1])
             if sl.stop == sl.start:
                 continue
-            r = orc.site_rates(states[:, sl], self.parent, self.blen, self.leaf, self.pi[l] / self.pi[l].sum(), self.exch[l])
+            r = orc.site_rates(states[:, sl], self.parent, self.blen, self.leaf, self.pi[l] / self.pi[l].sum(), self.exch[l], self.cat_rates, self.cat_weights)
             for k in out:
                 out[k][sl] = r[k]
         return out

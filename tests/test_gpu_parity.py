@@ -622,3 +622,62 @@ def test_locus_gradient_hessian_diagonal(oracle):
                 ref = (f(bp) - 2 * f(cb[c]) + f(bm)) / (h * h)
                 assert abs(d2[c, b] - ref) < 1e-4 * max(1.0, abs(ref)), (c, b, d2[c, b], ref)
     plan.close()
+
+
+def test_rate_mixture_vs_oracle(oracle):
+    """Opt-in GTR+G extension (tphip_plan_desc.ncat): L(s) = sum_k w_k L(s rho_k) inside the per-site optimiser, HIP vs
+    the oracle's restatement of the same mixture (1e-6 on rates, exact flags); categories that all equal 1 give the
+    plain model's answers; the diagnostic curve kernel (f, g, h at chosen u) agrees with the oracle's mixture too.
+    The reference's script has no mixture, so K = 1 is the only setting with reference parity."""
+    engine = _engine()
+    from tapir_amd import compute, synth
+    for ntaxa, ncols, seed in ((8, 700, 5), (40, 500, 6)):
+        d = synth.simulate(2, ncols, ntaxa, seed)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        st = d["states"].numpy()
+        r, w = compute.discrete_gamma(0.5, 4)
+        args = (ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"], [10], [[5, 15]])
+        plain = engine.Plan(*args, correction=pin["correction"])
+        ones = engine.Plan(*args, correction=pin["correction"], cat_rates=[1.0, 1.0, 1.0], cat_weights=[0.5, 0.25, 0.25])
+        mix = engine.Plan(*args, correction=pin["correction"], cat_rates=r, cat_weights=w)
+        a, b, c = plain.site_rates(st), ones.site_rates(st), mix.site_rates(st)
+        ok = a["flag"] == 0
+        assert np.array_equal(a["flag"], b["flag"]) and _rel(b["rate"][ok], a["rate"][ok], 1e-12).max() < 1e-9
+        assert np.abs(a["lnl"] - b["lnl"]).max() < 1e-9
+        lam, U, Ui, kappa = mix.models()
+        for l in range(2):
+            sl = slice(l * ncols, (l + 1) * ncols)
+            ref = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l], r, w)
+            assert np.array_equal(c["flag"][sl], ref["flag"])
+            okm = (ref["flag"] == 0) | (ref["flag"] == 3)
+            rel = _rel(c["rate"][sl][okm], ref["rate"][okm], 1e-12)
+            lnl_ok = np.abs(c["lnl"][sl] - ref["lnl"]) < 1e-9
+            # almost flat maxima cannot be located to 1e-6 by anyone: there the log-likelihoods must agree instead
+            assert np.all((rel < RTOL_RATE) | lnl_ok[okm]), rel.max()
+            assert lnl_ok.mean() > 0.99
+        assert np.abs(c["rate"] - a["rate"])[ok & (c["flag"] == 0)].max() > 1e-3     # the mixture does change the optimum
+        u = np.linspace(-2.0, 2.0, st.shape[1])
+        f, g, h = mix.eval_columns(st, u)
+        for col in (3, 77, ncols + 5):
+            l = col // ncols
+            fo, go, ho = _mixture_curve(oracle, st[:, l * ncols:(l + 1) * ncols], pin, d["pi"][l], d["exch"][l], col - l * ncols, u[col], r, w)
+            assert abs(f[col] - fo) < 1e-9 * max(1, abs(fo)) and abs(g[col] - go) < 1e-8 * max(1, abs(go))
+            assert abs(h[col] - ho) < 1e-7 * max(1, abs(ho))
+        for p in (plain, ones, mix):
+            p.close()
+    with pytest.raises(engine.TphipError, match="positive"):
+        engine.Plan(*args, cat_rates=[1.0, -1.0], cat_weights=[0.5, 0.5])
+
+
+def _mixture_curve(oracle, st, pin, pi, exch, col, u, rates, weights):
+    """f, g, h of the mixture at u from the oracle's single-category curve (independent of its own mixture code)."""
+    fk, gk, hk = [], [], []
+    for r in rates:
+        f, g, h = oracle.column_curve(st, pin["parent"], pin["blen"], pin["leaf"], pi, exch, col, np.array([u + np.log(r)]))
+        fk.append(f[0]); gk.append(g[0]); hk.append(h[0])
+    fk, gk, hk = np.array(fk) + np.log(weights), np.array(gk), np.array(hk)
+    top = fk.max()
+    p = np.exp(fk - top)
+    z = p.sum()
+    g = (p * gk).sum() / z
+    return top + np.log(z), g, (p * (hk + gk * gk)).sum() / z - g * g

@@ -541,3 +541,48 @@ def test_cli_two_ranks_gloo_matches_single_process(tmp_path):
         a = sqlite3.connect(outs[0] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
         b = sqlite3.connect(outs[1] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
         assert a == b and len(a) > 0
+
+
+def test_discrete_gamma_categories():
+    """Yang's discrete gamma for the opt-in rate mixture: mean 1, ordered, K = 1 is the identity, large alpha
+    collapses every category onto 1; known values for alpha = 0.5, K = 4 (Yang 1994, table 1 to 4 decimals)."""
+    from tapir_amd import compute
+    r, w = compute.discrete_gamma(0.5, 4)
+    assert np.allclose(w, 0.25) and abs((r * w).sum() - 1.0) < 1e-12 and np.all(np.diff(r) > 0)
+    assert np.allclose(r, [0.0334, 0.2519, 0.8203, 2.8944], atol=5e-5)
+    assert np.allclose(compute.discrete_gamma(0.5, 1)[0], [1.0])
+    assert np.allclose(compute.discrete_gamma(1e6, 4)[0], 1.0, atol=3e-3)
+
+
+def test_rate_mixture_in_the_oracle_and_cli(tmp_path):
+    """The mixture objective: categories that all equal 1 reproduce the plain model; a real discrete gamma changes
+    the optimum; and the command line's --gamma-categories reaches the engine (oracle stand-in here)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    from oracle import oracle as orc
+    from tapir_amd import cli, compute, synth
+    d = synth.simulate(2, 60, 6, 4)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()[:, :60]
+    a = orc.site_rates(st, pin["parent"], pin["blen"], pin["leaf"], d["pi"][0], d["exch"][0])
+    b = orc.site_rates(st, pin["parent"], pin["blen"], pin["leaf"], d["pi"][0], d["exch"][0], [1.0, 1.0, 1.0], [0.2, 0.3, 0.5])
+    ok = a["flag"] == 0
+    assert np.array_equal(a["flag"], b["flag"]) and np.abs(a["rate"] - b["rate"])[ok].max() < 1e-12
+    assert np.abs(a["lnl"] - b["lnl"]).max() < 1e-12
+    r, w = compute.discrete_gamma(0.5, 4)
+    c = orc.site_rates(st, pin["parent"], pin["blen"], pin["leaf"], d["pi"][0], d["exch"][0], r, w)
+    both = ok & (c["flag"] == 0)
+    assert both.sum() > 5 and np.abs(c["rate"] - a["rate"])[both].max() > 1e-3
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    tree = synth.write_nexus_dir(str(aln), d["states"].numpy(), d["locus_offsets"], d["names"], d["root"])
+    shutil.move(tree, tmp_path / "tree.newick")
+    outs = []
+    for extra in ([], ["--gamma-categories", "4", "--gamma-alpha", "0.5"]):
+        out = tmp_path / ("o%d" % len(outs))
+        out.mkdir()
+        cli.main([str(aln), str(tmp_path / "tree.newick"), "--output", str(out), "--times", "10", "--intervals", "5-15",
+                  "--exchangeabilities", "1,1,1,1,1,1"] + extra, engine_mod=oracle_engine)
+        f = sorted(x for x in os.listdir(out) if x.endswith(".rates"))[0]
+        outs.append(json.load(open(out / f))["sites"]["rates"])
+    assert any(abs(x["rate"] - y["rate"]) > 1e-3 for x, y in zip(*outs))
