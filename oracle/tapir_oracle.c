@@ -25,8 +25,8 @@
  *   orc_informative_counts           tapir/compute.py:96-106 (count of A/C/G/T cells per column)
  *
  * Optimiser policy (HyPhy's own derivative-free optimiser is not reproducible):
- *   maximise f(u) = log L(exp(u)) from u=0 (s=1) with a safeguarded Newton iteration that follows the
- *   uphill direction to the nearest local maximum.  Flags: 0 interior optimum, 1 flat (<=1 resolved
+ *   maximise f(u) = log L(exp(u)) from the column's parsimony rate (fitch_start; HyPhy: s=1) with a safeguarded
+ *   Newton iteration that follows the uphill direction to the nearest local maximum.  Flags: 0 interior optimum, 1 flat (<=1 resolved
  *   taxon: L does not depend on s, s stays 1), 2 saturated (log L flat to fp64 resolution on the way to
  *   s -> infinity, or still uphill at s = 1e4: s = 1e4 is reported), 3 optimum at s = 0 (all resolved
  *   taxa carry the same base), 4 iteration limit.
@@ -619,10 +619,42 @@ static void column_loglik(const orc_model *m, const orc_tree *tr, const uint8_t 
     *h = b / z - (*g) * (*g);
 }
 
-/* Safeguarded Newton on u = log s from u = 0, to the local maximum uphill of the start. */
+/* Start of the search: the rate at which the tree would carry the column's Fitch parsimony count,
+ * s0 = changes / (kappa * tree length * fraction of taxa present).  (HyPhy starts at siteRate = 1, bf:1050, usually
+ * e^3 away from the optimum; the maximum reached is the same, in fewer evaluations.)  Sets are 4-bit masks; a node's
+ * children are joined in node order. */
+static double fitch_start(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
+                          double chrono, int resolved) {
+    unsigned char *set = (unsigned char *)malloc((size_t)tr->nnodes);
+    int changes = 0;
+    for (int n = 0; n < tr->nnodes; ++n) {
+        if (tr->leaf_taxon[n] >= 0) {
+            unsigned mask = states[(int64_t)tr->leaf_taxon[n] * ncols + col] & 15u;
+            set[n] = (unsigned char)(mask ? mask : 15u);
+        } else set[n] = 0; /* no child joined yet */
+    }
+    for (int n = 0; n < tr->nnodes; ++n) { /* post-order: a node is complete before it is joined into its parent */
+        int p = tr->parent[n];
+        if (p < 0) continue;
+        if (set[p] == 0) set[p] = set[n];
+        else {
+            unsigned both = set[p] & set[n];
+            if (both) set[p] = (unsigned char)both; else { set[p] |= set[n]; ++changes; }
+        }
+    }
+    free(set);
+    const double len = m->kappa * chrono * ((double)(resolved > 0 ? resolved : 1) / (double)tr->ntaxa);
+    double u0 = (len > 0) ? log((double)(changes > 0 ? changes : 1) / len) : 0.0;
+    if (!(u0 == u0)) u0 = 0.0;
+    if (u0 < -20.0) u0 = -20.0;
+    if (u0 > 8.0) u0 = 8.0;
+    return u0;
+}
+
+/* Safeguarded Newton on u = log s from u_start, to the local maximum uphill of the start. */
 static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
-                            double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
-    double u = 0, lo = ORC_U_MIN, hi = ORC_U_MAX, f = 0, g, h;
+                            double u_start, double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
+    double u = u_start, lo = ORC_U_MIN, hi = ORC_U_MAX, f = 0, g, h;
     double u_prev = 0, h_prev = 0;
     int lo_open = 1, hi_open = 1, have_prev = 0; /* bracket ends not evaluated yet; previous point known */
     *flag_out = 4;
@@ -718,7 +750,7 @@ int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, 
             int x = (uni == 1) ? 0 : (uni == 2) ? 1 : (uni == 4) ? 2 : 3;
             s = 0.0; f = log(m.pi[x]); fl = 3;
         } else {
-            maximise_column(&m, &tr, states, ncols, c, &s, &f, &fl, &ne);
+            maximise_column(&m, &tr, states, ncols, c, fitch_start(&m, &tr, states, ncols, c, chrono, resolved), &s, &f, &fl, &ne);
         }
         total_eval += ne;
         rate[c] = s * m.kappa;

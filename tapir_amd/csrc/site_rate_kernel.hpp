@@ -2,7 +2,8 @@
 //
 // Reference behaviour replaced: tapir/data/models_and_rates.bf:1042-1070 -- for each alignment column
 // `Optimize(site_res, siteLikelihood)` over the single scalar siteRate that multiplies every branch length
-// of the fixed tree (bf:1003-1013), GTR model (bf:978-1001), start value 1 (bf:1050).
+// of the fixed tree (bf:1003-1013), GTR model (bf:978-1001); HyPhy's start value is 1 (bf:1050), here the column's
+// parsimony rate computed by classify_kernel (same maximum, one evaluation fewer).
 //
 // Mapping to CDNA4
 //   * one alignment column per lane, one wavefront per workgroup, all of one locus, so the locus'
@@ -480,7 +481,8 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         uint32_t pk[NW > 0 ? NW : 1] = {0};
 #pragma unroll
         for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
-        double u = 0.0, lo = kUMin, hi = kUMax, u_prev = 0.0, h_prev = 0.0;
+        // start: classify_kernel left the column's parsimony-based log rate in its `rate` slot (pi_kernels.hpp)
+        double u = done ? 0.0 : P.rate[col], lo = kUMin, hi = kUMax, u_prev = 0.0, h_prev = 0.0;
         bool lo_open = true, hi_open = true, have_prev = false;
         int it = 0;
         while (true) {
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     col = work[idx];
 #pragma unroll
                     for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
-                    u = 0.0; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; have_prev = false; it = 0;
+                    u = P.rate[col]; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; have_prev = false; it = 0;
                     done = false;
                 }
                 next += __popcll(free_mask);

@@ -400,7 +400,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     C.locus_offsets = p->d_offsets.p; C.chunk_locus = p->d_pi_chunk_locus.p; C.chunk_index = p->d_pi_chunk_index.p;
     C.rate = d_rate; C.subst = d_subst; C.lnl = d_lnl; C.flag = d_flag; C.nres = d_nres;
     C.chrono_length = p->prog.chrono_length;
-    C.tip_taxon = p->d_tip_taxon.p;
+    C.ops = p->d_ops.p; C.nops = (int32_t)p->prog.ops.size();
     C.packed = (uint32_t*)((char*)ws + p->ws_packed);
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
