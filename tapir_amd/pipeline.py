@@ -95,20 +95,35 @@ def _write_one(l):
     return l
 
 
+STAGE1_BLOCK_LOCI = 512   # loci fitted together: 512 x 202 models x 9-point stencils = 0.9 M candidates per call
+
+
 def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, blen, leaf, T, times, intervals,
-                                     correction, device=0):
-    """Stage 1 of models_and_rates.bf (bf:405-897) for every locus at once -> [L, 6] AC, AG(=1), AT, CG, CT, GT."""
+                                     correction, device=0, block_loci=None):
+    """Stage 1 of models_and_rates.bf (bf:405-897) for every locus -> [L, 6] AC, AG(=1), AT, CG, CT, GT.
+    Loci are independent, so they are fitted in blocks of `block_loci`: that bounds the optimiser's host memory and the
+    candidate batches (tens of thousands of loci would otherwise mean 10^7 candidates per likelihood call)."""
     from . import stage1
+    offsets = np.asarray(offsets, dtype=np.int64)
+    pi = np.asarray(pi, dtype=np.float64).reshape(-1, 4)
     L = len(offsets) - 1
-    # unique site patterns with counts, as HyPhy evaluates them (bf:960-963): every likelihood below runs on those
-    pstates, poffsets, weights, _ = eng.compress_columns(states, offsets, device=device, want_map=False)
-    plan = eng.Plan(ntaxa, parent, blen, leaf, poffsets, pi, np.ones((L, 6)), T, times, intervals,
-                    correction=correction, device=device)
-    try:
-        plan.set_column_weights(weights)
-        return stage1.model_averaged_exchangeabilities(plan, pstates, pi, parent, np.asarray(blen) / correction)["exch"]
-    finally:
-        plan.close()
+    step = int(block_loci or STAGE1_BLOCK_LOCI)
+    out = np.empty((L, 6))
+    for l0 in range(0, L, step):
+        l1 = min(L, l0 + step)
+        sub = np.ascontiguousarray(states[:, offsets[l0]:offsets[l1]])
+        off = offsets[l0:l1 + 1] - offsets[l0]
+        # unique site patterns with counts, as HyPhy evaluates them (bf:960-963): every likelihood below runs on those
+        pstates, poffsets, weights, _ = eng.compress_columns(sub, off, device=device, want_map=False)
+        plan = eng.Plan(ntaxa, parent, blen, leaf, poffsets, pi[l0:l1], np.ones((l1 - l0, 6)), T, times, intervals,
+                        correction=correction, device=device)
+        try:
+            plan.set_column_weights(weights)
+            out[l0:l1] = stage1.model_averaged_exchangeabilities(plan, pstates, pi[l0:l1], parent,
+                                                                 np.asarray(blen) / correction)["exch"]
+        finally:
+            plan.close()
+    return out
 
 
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,

@@ -586,3 +586,18 @@ def test_rate_mixture_in_the_oracle_and_cli(tmp_path):
         f = sorted(x for x in os.listdir(out) if x.endswith(".rates"))[0]
         outs.append(json.load(open(out / f))["sites"]["rates"])
     assert any(abs(x["rate"] - y["rate"]) > 1e-3 for x, y in zip(*outs))
+
+
+def test_stage1_blocks_of_loci_give_the_same_rates():
+    """pipeline.model_averaged_exchangeabilities fits loci in blocks (bounded candidate batches); loci are
+    independent, so the block size must not change any locus' estimate."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_engine
+    from tapir_amd import pipeline, synth
+    d = synth.simulate(3, 50, 4, 12)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    args = (oracle_engine, d["states"].numpy(), d["locus_offsets"], d["pi"], 4, pin["parent"], pin["blen"], pin["leaf"], pin["T"],
+            [1], [[0, 1]], pin["correction"])
+    a = pipeline.model_averaged_exchangeabilities(*args)
+    b = pipeline.model_averaged_exchangeabilities(*args, block_loci=2)
+    assert a.shape == (3, 6) and np.max(np.abs(a - b) / a) < 1e-6
