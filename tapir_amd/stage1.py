@@ -22,6 +22,8 @@ Parity: HyPhy's own optimiser and its results for this stage are pinned by no fi
 ("parity unpinned"); the stage is checked against an independent CPU restatement
 (tests/test_gpu_stage1.py: oracle likelihood + scipy L-BFGS-B) at 1e-3 relative on the averaged rates.
 """
+import os
+
 import numpy as np
 
 RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
@@ -31,6 +33,7 @@ RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
 LOG_RATE_MIN, LOG_RATE_MAX = -7.0, 9.2      # exchangeabilities within [9e-4, 1e4]
 LOG_BLEN_MIN, LOG_BLEN_MAX = -23.0, 4.0     # branch lengths within [1e-10, 55]
 MAX_LOG_STEP = 2.0                          # largest move of a log-parameter in one iteration
+ESCAPE_LENGTH = 1e-3                        # where a wrongly collapsed branch is put back (Stage1._grm_escape)
 PRUNE_NATS = 30.0                           # see Stage1.fit_submodels
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
 
@@ -83,8 +86,10 @@ class _LBFGS:
     """Batched L-BFGS (maximisation written as minimisation of -lnL) over P independent problems of dimension D.
     `value(X, idx)` evaluates points X[len(idx), D] of problems idx; `value_and_grad(X, idx)` adds gradients."""
 
-    def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=2e-6,
-                 lo=-np.inf, hi=np.inf, prune=None):
+    def __init__(self, value, value_and_grad, x0, active=None, history=8, maxit=200, ftol=1e-10, gtol=2e-6, ptol=1e-9,
+                 lo=-np.inf, hi=np.inf, prune=None, escape=None):
+        self.escape = escape  # optional: escape(problem indices, x, g) -> (x', moved mask): called on problems about to stop
+        self.ptol = ptol      # stop when the quasi-Newton model predicts a further decrease below ptol * (1 + |f|)
         self.prune = prune   # optional: prune(problem indices, f, last decrease) -> mask of problems to abandon
         self.value, self.vg = value, value_and_grad
         self.x = np.array(x0, dtype=np.float64)
@@ -110,6 +115,8 @@ class _LBFGS:
         gamma_all = np.ones(P)
         nhist = np.zeros(P, dtype=np.int64)
         converged = np.zeros(P, bool)
+        last_df = np.full(P, np.inf)
+        fresh = np.zeros(P, bool)        # history was just reset after a failed line search
         self.iters = np.zeros(P, dtype=np.int64)
         for it in range(self.maxit):
             live = np.flatnonzero(~converged)
@@ -144,6 +151,39 @@ class _LBFGS:
             if bad.any():
                 d[bad] = -gl[bad]
                 gd[bad] = -(gl[bad] ** 2).sum(1)
+            # Convergence: the last step gained (almost) nothing AND the quasi-Newton model, whose metric knows about
+            # flat directions (branches collapsing to zero have tiny gradients and tiny curvatures alike), predicts that
+            # the next one will not either.  A test on the raw gradient norm stops early exactly on those directions.
+            scale_f = 1.0 + np.abs(fl)
+            gmax = np.abs(gl).max(1)
+            stop = (last_df[sl] <= self.ftol * scale_f) & (-gd <= self.ptol * scale_f) & (gmax <= self.gtol * scale_f)
+            stop |= gmax <= 1e-9
+            if stop.any() and self.escape is not None:
+                # a stopping point may be a trap of the parametrisation rather than an optimum: let the objective move it
+                xs, moved = self.escape(live[stop], xl[stop], gl[stop])
+                if moved.any():
+                    mi = live[stop][moved]
+                    self.x[mi] = xs[moved]
+                    fm, gm, hm = self._vg(self.x[mi], mi)
+                    f[mi] = fm
+                    g[mi] = np.where(self.active[mi], gm, 0.0)
+                    if hm is not None:
+                        hdiag[mi] = hm
+                    rho[:, mi] = 0.0
+                    nhist[mi] = 0
+                    last_df[mi] = np.inf
+                    continue          # recompute every direction from the new points
+            if stop.any():
+                if os.environ.get("TPHIP_STAGE1_TRACE") and P <= 16:
+                    print("it %d stop %s last_df %s -gd %s" % (it, live[stop].tolist(), last_df[live[stop]].tolist(), (-gd[stop]).tolist()), flush=True)
+                converged[live[stop]] = True
+                if stop.all():
+                    continue
+                keep = ~stop
+                live = live[keep]
+                sl = live
+                xl, fl, gl, d, gd, hl, have_h = xl[keep], fl[keep], gl[keep], d[keep], gd[keep], hl[keep], have_h[keep]
+                gamma = gamma[keep]
             # first iteration: a cautious step length
             step0 = np.where((nhist[sl] == 0) & ~have_h, np.minimum(1.0, 1.0 / np.maximum(np.abs(gl).max(1), 1e-300)), 1.0)
             # cap the step in log-parameter space
@@ -180,14 +220,26 @@ class _LBFGS:
             gamma_all[sl] = np.where(upd, sy / np.maximum(yy, 1e-300), gamma)
             nhist[sl] += upd
             df = fl - fx
-            gmax = np.abs(gx).max(1)
-            done = failed | ((df <= self.ftol * (1.0 + np.abs(fx))) & (gmax <= self.gtol * (1.0 + np.abs(fx))))
-            done |= gmax <= 1e-9
+            last_df[sl] = np.where(failed, 0.0, df)
+            # a failed line search with correction pairs in play: forget them and try once more along the
+            # (preconditioned) gradient before giving the point up as converged
+            retry = failed & (nhist[sl] > 0)
+            if retry.any():
+                rho[:, live[retry]] = 0.0
+                nhist[live[retry]] = 0
+                last_df[live[retry]] = np.inf
+            done = failed & ~retry & fresh[sl]
+            done |= failed & ~retry & (nhist[sl] == 0)
+            fresh[sl] = retry
             if self.prune is not None:
                 done |= self.prune(live, fx, df)
             self.x[sl] = xnew; f[sl] = fx; g[sl] = gx
             self.iters[sl] += 1
             converged[live[done]] = True
+            if os.environ.get("TPHIP_STAGE1_TRACE") and P <= 16:
+                print("it %d live %s f %s df %s -gd %s failed %s retry %s done %s" % (
+                    it, live.tolist(), np.round(fx, 6).tolist(), ["%.2e" % v for v in df], ["%.2e" % v for v in -gd],
+                    failed.astype(int).tolist(), retry.astype(int).tolist(), done.astype(int).tolist()), flush=True)
         self.f, self.g = f, g
         return self.x, f
 
@@ -256,6 +308,9 @@ class Stage1:
             out = self.plan.locus_gradient(self.states, vecs, idx, exch, None, scale, cache=self.cache,
                                            curvature=self.precondition)
             lnl, dex, dlt, sdl = out[:4]
+            if not hasattr(self, "_last_f"):
+                self._last_f = np.zeros(self.plan.nloci)
+            self._last_f[idx] = -lnl
             # t_b = b_b / totalFactor(r): d log t_b / d r_q = -(2 pi_i pi_j) / totalFactor for every branch
             pi = self.pi[idx]
             dk = np.stack([2.0 * pi[:, i] * pi[:, j] for i, j in _PAIRS], axis=1)
@@ -293,6 +348,24 @@ class Stage1:
         g = (f[:, 1::2] - f[:, 2::2]) / (2 * h)
         return f[:, 0], g
 
+    def _grm_escape(self, idx, X, G):
+        """Log-parameters have a trap at zero: d f / d log b = b * d f / d b vanishes with b whatever d f / d b is, so a
+        branch that overshot towards zero early on can sit there although the likelihood wants it longer (seen on 64
+        taxa x 200 columns: 0.08 lnL left on the table).  At a would-be stopping point every collapsed branch is
+        checked in the ORIGINAL parametrisation (optimality at the bound b = 0 needs d f / d b >= 0); offenders are
+        put back at a small positive length and the search continues from there."""
+        Xn = X.copy()
+        logb = X[:, 5:]
+        b = np.exp(logb)
+        slope = G[:, 5:] / b                                 # d(-lnL) / d b
+        fscale = 1.0 + np.abs(self._last_f[idx]) if hasattr(self, "_last_f") else 1.0
+        kick = (b < 1e-6) & (slope * ESCAPE_LENGTH < -1e-7 * np.reshape(fscale, (-1, 1)))
+        kick &= self._kicks[idx][:, None] < 3                # a branch that keeps coming back really is zero
+        Xn[:, 5:] = np.where(kick, np.log(ESCAPE_LENGTH), logb)
+        moved = kick.any(axis=1)
+        self._kicks[idx] += moved
+        return Xn, moved
+
     def initial_branch_lengths(self):
         """Start of the branch-length search: the input tree's shape (its lengths are in time units, not in
         substitutions), rescaled per locus to the best of a coarse grid of mean branch lengths 1e-4 .. 1 under the
@@ -316,7 +389,9 @@ class Stage1:
         x0[:, 5:] = np.log(self.initial_branch_lengths()[:, self.branches] * total_factor(self.pi, np.ones(6))[:, None])
         lo = np.concatenate([np.full(5, LOG_RATE_MIN), np.full(len(self.branches), LOG_BLEN_MIN)])
         hi = np.concatenate([np.full(5, LOG_RATE_MAX), np.full(len(self.branches), LOG_BLEN_MAX)])
-        opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi)
+        self._kicks = np.zeros(L, dtype=np.int64)
+        opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi,
+                     escape=self._grm_escape if self.analytic else None)
         x, f = opt.run()
         self.grm_iters = opt.iters
         exch = self._exch_from_free(x[:, :5])
