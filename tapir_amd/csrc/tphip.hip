@@ -88,6 +88,12 @@ struct tphip_plan {
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
     DevBuf<int32_t> d_tip_taxon, d_op_node;
+    // launch configuration of the locus likelihood / gradient kernels, fixed at plan creation (tuning knobs are read
+    // from the environment once, there): LDS bytes, whether the gradient kernel stages its state masks, resident
+    // gradient blocks per CU, forced slice count (0 = automatic)
+    size_t lik_lds = 0, grad_lds = 0;
+    int32_t lik_stage = 0, grad_stage = 0, grad_blocks_per_cu = 1, lik_nsplit_forced = 0;
+    bool lik_ok = false, grad_ok = false;
     int32_t ncat = 0;
     DevBuf<double> d_cat;     // [2 * ncat] category rates, then log weights
     DevBuf<int4> d_lik_ops;   // {code, taxon, node, tape slot} per op for the locus likelihood / gradient kernels
@@ -296,6 +302,34 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         p->site_waves = per_cu * prop.multiProcessorCount;
         p->num_cus = prop.multiProcessorCount;
+        // locus likelihood (value) kernel: staging the state masks in LDS costs it more than it saves (measured 13.6 ms
+        // vs 10.0 ms per 1616 candidates x 20000 columns x 64 taxa); opt-in for experiments
+        p->lik_lds = ((size_t)p->nnodes * 4 + (size_t)p->prog.stack_depth * 4 * kLikBlock) * sizeof(double);
+        const size_t lik_stage_bytes = (size_t)p->ntaxa * kLikBlock;
+        p->lik_stage = (getenv("TPHIP_LIK_STAGE") && lik_stage_bytes <= 48 * 1024 && p->lik_lds + lik_stage_bytes <= 150 * 1024) ? 1 : 0;
+        if (p->lik_stage) p->lik_lds += lik_stage_bytes;
+        p->lik_ok = p->lik_lds <= 150 * 1024;
+        if (p->lik_ok && p->lik_lds > 64 * 1024)
+            p->lik_ok = hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        // gradient kernel: staging helps it (95.6 -> 91.7 ms)
+        p->grad_lds = (size_t)p->nnodes * (kGradEF + 2 * kGradWaves * kGradSlots) * sizeof(double);
+        const size_t grad_stage_bytes = (size_t)p->ntaxa * kGradBlock;
+        p->grad_stage = (!getenv("TPHIP_LIK_NO_STAGE") && grad_stage_bytes <= 48 * 1024 && p->grad_lds + grad_stage_bytes <= 150 * 1024) ? 1 : 0;
+        if (p->grad_stage) p->grad_lds += grad_stage_bytes;
+        p->grad_ok = p->grad_lds <= 150 * 1024;
+        if (p->grad_ok && p->grad_lds > 64 * 1024)
+            p->grad_ok = hipFuncSetAttribute((const void*)locus_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        if (p->grad_ok) {
+            int bpc = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, locus_grad_kernel, kGradBlock, p->grad_lds) != hipSuccess || bpc < 1) bpc = 1;
+            // the tape of the resident blocks should stay within reach of the 256 MB memory-side cache: with 64 taxa, 4
+            // blocks per CU (390 MB of tape) ran slower than 3 (91 vs 85 ms); fewer than 3 loses more to latency
+            const size_t tape_per_block = (size_t)std::max(1, p->prog.ntape + p->prog.stack_depth) * 4 * kGradBlock * sizeof(double);
+            if (tape_per_block * (size_t)p->num_cus * (size_t)bpc > ((size_t)300 << 20)) bpc = std::min(bpc, 3);
+            if (const char* env = getenv("TPHIP_GRAD_BLOCKS_PER_CU")) bpc = std::max(1, atoi(env));
+            p->grad_blocks_per_cu = bpc;
+        }
+        if (const char* env = getenv("TPHIP_LIK_NSPLIT")) p->lik_nsplit_forced = std::max(1, atoi(env));
         // Small batches (an equal share would be under ~1000 columns) run one workgroup per locus-aligned
         // slice instead: cutting a small locus in two doubles its prologue and drain (measured on C2).
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
@@ -539,7 +573,7 @@ int tphip_quad_townsend_dev(int32_t device, const double* d_rates, int64_t n, do
 // Slices per candidate for the locus likelihood / gradient kernels: enough work items to fill the device even when
 // only a few candidates are in flight (the general model's one point per locus), never more than a locus has blocks.
 static int lik_nsplit(const tphip_plan* p, int64_t ncand, int block) {
-    if (const char* env = getenv("TPHIP_LIK_NSPLIT")) return std::max(1, atoi(env));
+    if (p->lik_nsplit_forced > 0) return p->lik_nsplit_forced;
     const int64_t target = (int64_t)p->num_cus * 8;
     int64_t ns = (target + ncand - 1) / std::max<int64_t>(ncand, 1);
     const int64_t max_blocks = std::max<int64_t>(1, (p->max_locus_cols + block - 1) / block);
@@ -572,18 +606,9 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
     L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
     L.cand_pfac = d_cand_pfac; L.out = d_out;
-    size_t lds = ((size_t)p->nnodes * 4 + (size_t)p->prog.stack_depth * 4 * kLikBlock) * sizeof(double);
-    const size_t stage = (size_t)p->ntaxa * kLikBlock;
-    // staging the state masks in LDS costs this kernel more than it saves (measured: 13.6 ms vs 10.0 ms per 1616
-    // candidates x 20000 columns x 64 taxa): its tip loads are already covered by other waves.  Opt-in for experiments.
-    L.stage_states = (getenv("TPHIP_LIK_STAGE") && stage <= 48 * 1024 && lds + stage <= 150 * 1024) ? 1 : 0;
-    if (L.stage_states) lds += stage;
-    if (lds > 150 * 1024) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-likelihood kernel's LDS tables");
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    if (!p->lik_ok) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-likelihood kernel's LDS tables");
+    const size_t lds = p->lik_lds;
+    L.stage_states = p->lik_stage;
     const int nsplit = lik_nsplit(p, ncand, kLikBlock);
     L.nsplit = nsplit;
     if (nsplit > 1) {
@@ -627,28 +652,10 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     L.cand_pfac = d_cand_pfac; L.out = d_lnl;
     G.ntape = p->prog.ntape; G.ncand = ncand;
     G.out_dexch = d_dexch; G.out_dlogt = d_dlogt; G.out_sum_dlogt = d_sum_dlogt; G.out_d2logt = d_d2logt;
-    size_t lds = (size_t)p->nnodes * (kGradEF + 2 * kGradWaves * kGradSlots) * sizeof(double);
-    const size_t stage = (size_t)p->ntaxa * kGradBlock;
-    L.stage_states = (stage <= 48 * 1024 && lds + stage <= 150 * 1024) ? 1 : 0;
-    if (getenv("TPHIP_LIK_NO_STAGE")) L.stage_states = 0;
-    if (L.stage_states) lds += stage;
-    if (lds > 150 * 1024) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-gradient kernel's LDS tables");
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)locus_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
-    // resident workgroups loop over the candidates; each owns one tape
-    int blocks_per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, locus_grad_kernel, kGradBlock, lds) != hipSuccess || blocks_per_cu < 1)
-        blocks_per_cu = 1;
-    // the tape of the resident blocks should stay within reach of the 256 MB memory-side cache: with 64 taxa, 4 blocks
-    // per CU (390 MB of tape) ran slower than 3 (measured 91 vs 85 ms); fewer than 3 loses more to latency than it gains
-    {
-        const size_t tape_per_block = (size_t)std::max(1, p->prog.ntape + p->prog.stack_depth) * 4 * kGradBlock * sizeof(double);
-        if (tape_per_block * (size_t)p->num_cus * (size_t)blocks_per_cu > ((size_t)300 << 20)) blocks_per_cu = std::min(blocks_per_cu, 3);
-    }
-    if (const char* env = getenv("TPHIP_GRAD_BLOCKS_PER_CU")) blocks_per_cu = std::max(1, atoi(env));
+    if (!p->grad_ok) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-gradient kernel's LDS tables");
+    const size_t lds = p->grad_lds;
+    L.stage_states = p->grad_stage;
+    const int blocks_per_cu = p->grad_blocks_per_cu;   // resident workgroups loop over the candidates; each owns one tape
     const int nsplit = lik_nsplit(p, ncand, kGradBlock);
     L.nsplit = nsplit;
     const size_t nn = (size_t)p->nnodes, items = (size_t)ncand * nsplit;
