@@ -23,6 +23,7 @@ Parity: HyPhy's own optimiser and its results for this stage are pinned by no fi
 (tests/test_gpu_stage1.py: oracle likelihood + scipy L-BFGS-B) at 1e-3 relative on the averaged rates.
 """
 import os
+import time
 
 import numpy as np
 
@@ -264,6 +265,7 @@ class Stage1:
         # which is what one reverse-mode gradient costs at present (measured, tools/stage1_timing.py), so they default
         # to the stencil; the general model (5 + 2N-3 parameters) always uses the gradient kernel
         self.sub_analytic = (analytic is True and sub_analytic is not False) if sub_analytic is None else sub_analytic
+        self.lik_seconds = 0.0       # wall time spent inside likelihood calls (kernels + copies)
         self.prune_models = prune_models
         self.precondition = precondition
         self.ngrads = 0
@@ -276,7 +278,10 @@ class Stage1:
     # ---- likelihood calls ---------------------------------------------------------------------------------
     def _lik(self, vecs, locus, exch, vec=None, scale=None, pidx=None, pfac=None):
         self.nevals += len(locus)
-        return self.plan.locus_loglik(self.states, vecs, locus, exch, vec, scale, pidx, pfac, cache=self.cache)
+        t0 = time.perf_counter()
+        out = self.plan.locus_loglik(self.states, vecs, locus, exch, vec, scale, pidx, pfac, cache=self.cache)
+        self.lik_seconds += time.perf_counter() - t0
+        return out
 
     @staticmethod
     def _exch_from_free(logr5):
@@ -403,13 +408,13 @@ class Stage1:
     def _sub_exch(self, X, cls):
         """free log class rates X [n, 4] + class map cls [n, 6] -> exchangeabilities [n, 6]."""
         r = np.exp(X)
-        pick = np.take_along_axis(r, np.maximum(cls, 0), axis=1)
+        pick = r[np.arange(len(X))[:, None], np.maximum(cls, 0)]
         return np.where(cls < 0, 1.0, pick)
 
     def _sub_eval(self, X, prob, cls):
         exch = self._sub_exch(X, cls)
         loc = self._sub_locus[prob]
-        scale = 1.0 / total_factor(self.pi[loc], exch)
+        scale = 1.0 / (exch * self._w6[loc]).sum(axis=1)      # branch lengths = stash / totalFactor(model), bf:613-619
         return exch, loc, scale
 
     def _sub_value(self, X, idx):
@@ -425,28 +430,24 @@ class Stage1:
             lnl, dex, _, sdl = self.plan.locus_gradient(self.states, self._stash, loc, exch, loc, scale, cache=self.cache,
                                                         per_branch=False)
             # t_b = stash_b / totalFactor(r): d log t_b / d r_q = -(2 pi_i pi_j) / totalFactor for every branch
-            pi = self.pi[loc]
-            dk = np.stack([2.0 * pi[:, i] * pi[:, j] for i, j in _PAIRS], axis=1)
-            dr = (dex - sdl[:, None] * dk * scale[:, None]) * exch              # d lnL / d log r_q, q over the six rates
+            dr = (dex - sdl[:, None] * self._w6[loc] * scale[:, None]) * exch    # d lnL / d log r_q, q over the six rates
             g = np.zeros((n, D))
             for c in range(D):
                 g[:, c] = (dr * (cls == c)).sum(1)
             return -lnl, -np.where(self._sub_active[idx], g, 0.0)
-        h = self.h
+        # central differences: the stencil's exchangeabilities are the base point's times precomputed factors
+        # (member rates of class j times e^{+-h}), so a whole iteration's candidates are two broadcasts
         per = 1 + 2 * D
-        Xr = np.repeat(X[:, None, :], per, axis=1)
-        for j in range(D):
-            Xr[:, 1 + 2 * j, j] += h
-            Xr[:, 2 + 2 * j, j] -= h
-        pr = np.repeat(idx, per)
-        exch, loc, scale = self._sub_eval(Xr.reshape(-1, D), pr, self._sub_cls[pr])
+        base = self._sub_exch(X, self._sub_cls[idx])                             # [n, 6]
+        exch = (base[:, None, :] * self._sub_stencil[idx]).reshape(n * per, 6)   # [n * per, 6]
+        loc = np.repeat(self._sub_locus[idx], per)
+        scale = 1.0 / (exch * self._w6[loc]).sum(axis=1)
         # skip the stencil points of inactive dimensions (their gradient is defined as zero)
-        act = np.repeat(self._sub_active[idx][:, None, :], 2, axis=2).reshape(n, 2 * D)
-        need = np.concatenate([np.ones((n, 1), bool), act], axis=1).reshape(-1)
+        need = self._sub_need[idx].reshape(-1)
         f = np.zeros(n * per)
         f[need] = -self._lik(self._stash, loc[need], exch[need], loc[need], scale[need])
         f = f.reshape(n, per)
-        g = (f[:, 1::2] - f[:, 2::2]) / (2 * h)
+        g = (f[:, 1::2] - f[:, 2::2]) / (2 * self.h)
         return f[:, 0], np.where(self._sub_active[idx], g, 0.0)
 
     def fit_submodels(self, grm_exch, grm_t, maxit=100, grm_lnl=None):
@@ -460,6 +461,19 @@ class Stage1:
         self._sub_cls = np.tile(cls[1:], (L, 1))
         kk = np.tile(k[1:], L)
         self._sub_active = np.arange(4)[None, :] < kk[:, None]
+        self._w6 = np.stack([2.0 * self.pi[:, i] * self.pi[:, j] for i, j in _PAIRS], axis=1)   # totalFactor = exch . w6
+        # per model: factors of the 9-point stencil [1 + 2*4, 6] and which of its points are needed
+        up, dn = np.exp(self.h), np.exp(-self.h)
+        sten = np.ones((M, 9, 6))
+        need = np.zeros((M, 9), bool)
+        need[:, 0] = True
+        for j in range(4):
+            member = cls[1:] == j                                   # [M, 6]
+            sten[:, 1 + 2 * j, :] = np.where(member, up, 1.0)
+            sten[:, 2 + 2 * j, :] = np.where(member, dn, 1.0)
+            need[:, 1 + 2 * j] = need[:, 2 + 2 * j] = k[1:] > j
+        self._sub_stencil = np.tile(sten, (L, 1, 1))
+        self._sub_need = np.tile(need, (L, 1))
         # start: geometric mean of the general model's rates over each class
         lg = np.log(grm_exch)[self._sub_locus]                        # [P, 6]
         x0 = np.zeros((L * M, 4))

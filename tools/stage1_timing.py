@@ -16,12 +16,13 @@ analytic = None if len(sys.argv) < 5 else (sys.argv[4] == "analytic")
 s1 = stage1.Stage1(plan, st, pi, pin["parent"], np.asarray(pin["blen"]) / pin["correction"], analytic=analytic,
                    precondition=os.environ.get("S1_NO_PRECOND") is None)
 t0 = time.time(); ge, gt, gl = s1.fit_grm(); t1 = time.time()
-e1, g1 = s1.nevals, s1.ngrads
+e1, g1, l1 = s1.nevals, s1.ngrads, s1.lik_seconds
 sub = s1.fit_submodels(ge, gt, grm_lnl=gl); t2 = time.time()
 print("loci %d cols %d taxa %d" % (L, n, nt))
 print("gradients: general model %d, rate-class models %d" % (g1, s1.ngrads - g1))
 print("general model: %.2f s, %d likelihood evaluations, iterations max %d mean %.1f" % (t1 - t0, e1, s1.grm_iters.max(), s1.grm_iters.mean()))
 print("202 models   : %.2f s, %d likelihood evaluations, iterations max %d mean %.1f" % (t2 - t1, s1.nevals - e1, s1.sub_iters.max(), s1.sub_iters.mean()))
+print("inside likelihood calls (value kernel + copies): general model %.2f s, 202 models %.2f s" % (l1, s1.lik_seconds - l1))
 print("models abandoned early: %d of %d" % (getattr(s1, "pruned", 0), L * 202))
 print("column-evaluations/s: %.3e" % (s1.nevals * n / (t2 - t0)))
 true = np.asarray(d["exch"]); print("max rel err of general-model rates vs generating:", np.max(np.abs(ge - true / true[:, 1:2]) / true))
