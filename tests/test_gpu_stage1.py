@@ -175,3 +175,42 @@ def test_stage1_degenerate_loci_stay_finite():
     e2 = pipeline.model_averaged_exchangeabilities(engine, two, np.array([0, 400]), np.full((1, 4), 0.25), 2, parent, blen, leaf,
                                                    30, [1], [[0, 1]], 1.0)
     assert np.all(np.isfinite(e2)) and e2[0, 1] == 1.0
+
+
+def test_stage1_fullsize_properties():
+    """Stage 1 at the C3 shape (50 000 columns x 64 taxa per locus; 4 loci), through size-independent properties:
+    the general model's point is stationary (gradient kernel at the returned point), nesting holds (no constrained
+    model beats the general one), weights are a distribution, the averaged rates lie within the range of the models'
+    rates, and the optimum does not depend on how many loci are fitted together."""
+    engine = _engine()
+    from tapir_amd import nexus, stage1, synth
+    L, n, nt = 4, 50000, 64
+    d = synth.simulate(L, n, nt, synth.WORKLOAD_SEED["C3"], device="cuda")
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].cpu().numpy()
+    pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, d["locus_offsets"]))
+    blen = np.asarray(pin["blen"]) / pin["correction"]
+    plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"], [1], [[0, 1]],
+                       correction=pin["correction"])
+    res = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen)
+    lnl, w, exch = res["lnl"], res["weights"], res["exch"]
+    assert np.allclose(w.sum(1), 1.0) and np.all(w >= 0) and np.all(exch[:, 1] == 1.0)
+    assert np.all(lnl[:, 1:] <= lnl[:, :1] + 1e-3 * (1 + np.abs(lnl[:, :1]) * 1e-6))       # nested models
+    lo, hi = res["model_exch"].min(axis=1), res["model_exch"].max(axis=1)
+    assert np.all(exch >= lo - 1e-12) and np.all(exch <= hi + 1e-12)
+    # stationarity of the general model in (log rates, log lengths)
+    ge, gt = res["grm_exch"], res["grm_blen"]
+    val, dex, dlt, _ = plan.locus_gradient(st, gt, np.arange(L), ge)
+    assert np.max(np.abs(val - lnl[:, 0]) / np.abs(val)) < 1e-9
+    br = np.asarray(pin["parent"]) >= 0
+    glog = np.concatenate([dex[:, [0, 2, 3, 4, 5]] * ge[:, [0, 2, 3, 4, 5]], dlt[:, br]], axis=1)
+    # branches at the lower bound may keep a (small, inward-pointing) gradient; everything else must vanish
+    free = np.concatenate([np.ones((L, 5), bool), gt[:, br] > 2e-10], axis=1)
+    assert np.max(np.abs(glog[free])) < 2e-6 * np.abs(val).max(), np.max(np.abs(glog[free]))
+    # one locus alone
+    one = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], [0, n], pi[:1], np.ones((1, 6)), pin["T"], [1], [[0, 1]],
+                      correction=pin["correction"])
+    alone = stage1.model_averaged_exchangeabilities(one, st[:, :n], pi[:1], pin["parent"], blen)["exch"]
+    assert np.max(np.abs(alone[0] - exch[0]) / exch[0]) < 1e-4
+    plan.close()
+    one.close()
