@@ -312,7 +312,10 @@ __device__ inline double lik_rcp(double v) {   // 1/v to < 1 ulp-ish: hardware e
     return r;
 }
 
-__global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_kernel(GradParams G) {
+// The parameter block is passed by pointer: 25 pointers and sizes by value would sit in ~60 scalar registers for the
+// whole kernel, next to the 48 of the eigenvectors, and spill into vector-register lanes inside the sweeps.
+__global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_kernel(const GradParams* __restrict__ Gp) {
+    const GradParams& G = *Gp;
     const LikParams& P = G.L;
     extern __shared__ double lds[];
     const int nn = P.nnodes;

@@ -104,6 +104,7 @@ struct tphip_plan {
     char* d_arena = nullptr;
     char* h_arena = nullptr;
     size_t arena_bytes = 0;
+    void* d_grad_params = nullptr;   // device copy of the gradient kernel's parameter block
     double* d_col_weight = nullptr;  // optional column multiplicities for the locus likelihood / gradient kernels
     double* d_part = nullptr;   // per-slice partial sums of the locus likelihood / gradient kernels, grown on demand
     size_t part_bytes = 0;
@@ -149,6 +150,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
+    if (plan->d_grad_params) { (void)hipFree(plan->d_grad_params); plan->d_grad_params = nullptr; }
     if (plan->d_arena) { (void)hipFree(plan->d_arena); plan->d_arena = nullptr; }
     if (plan->h_arena) { (void)hipHostFree(plan->h_arena); plan->h_arena = nullptr; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
@@ -452,12 +454,12 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.work_prefix = (const int64_t*)((char*)ws + p->ws_work_prefix); S.nloci = p->nloci;
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    S.persistent = p->site_persistent;
+    S.ncat = p->ncat; S.cat = p->d_cat.p;
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_site_chunks > 0) {
         const dim3 grid((unsigned)(p->site_persistent ? p->site_waves : p->n_site_chunks)), block(kSiteBlock);
-        S.persistent = p->site_persistent;
-        S.ncat = p->ncat; S.cat = p->d_cat.p;
         // register-resident tip states for up to 256 tips; beyond that the byte path (NW = 0)
         const char* fb = getenv("TPHIP_FORCE_BYTE_PATH");  // test/tuning knob: exercise the NW = 0 kernel on any tree
         if (fb && fb[0] == '1') site_rate_kernel<0><<<grid, block, lds, st>>>(S);
@@ -676,7 +678,9 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
         p->tape_bytes = need;
     }
     G.tape = p->d_tape;
-    locus_grad_kernel<<<dim3((unsigned)grid), dim3(kGradBlock), lds, (hipStream_t)stream>>>(G);
+    if (!p->d_grad_params) HIP_TRY(hipMalloc((void**)&p->d_grad_params, sizeof(GradParams)));
+    HIP_TRY(hipMemcpyAsync(p->d_grad_params, &G, sizeof(GradParams), hipMemcpyHostToDevice, (hipStream_t)stream));
+    locus_grad_kernel<<<dim3((unsigned)grid), dim3(kGradBlock), lds, (hipStream_t)stream>>>((const GradParams*)p->d_grad_params);
     HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
         auto sum = [&](const double* part, double* out, int width) {
