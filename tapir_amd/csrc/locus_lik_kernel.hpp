@@ -24,6 +24,10 @@
 namespace tphip {
 
 constexpr int kLikBlock = 128;
+// A partial is rescaled when its largest entry falls below this.  Two partials meet in a POP_MUL before the next check,
+// so the threshold must keep the PRODUCT of two just-unscaled partials above the smallest normal number (1e-308):
+// 1e-200 let a 400-taxon tree underflow to L = 0.
+constexpr double kLikRescaleBelow = 1e-100;
 constexpr double kLikTiny = 1e-300;   // floor of a tip message entry (see the tip arm of the kernels)
 
 struct LikParams {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
                     acc[i] *= fmax(fma(U[i * 4 + 3], z[3], fma(U[i * 4 + 2], z[2], fma(U[i * 4 + 1], z[1], U[i * 4] * z[0]))), kLikTiny);
             } else if (op.x == OP_BRANCH) {
                 const double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
-                if (mx < 1e-200 && mx > 0) {   // rescale (deep trees); rare, lane-divergent is fine here
+                if (mx < kLikRescaleBelow && mx > 0) {   // rescale (deep trees); rare, lane-divergent is fine here
                     int e;
                     frexp(mx, &e);
                     for (int i = 0; i < 4; ++i) acc[i] = ldexp(acc[i], -e);
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(kLikBlock) void locus_loglik_kernel(LikParams P) {
 constexpr int kGradBlock = 128;
 constexpr int kGradWaves = kGradBlock / 64;
 constexpr int kGradEF = 12;     // per node: e^{lam_k t}[4], F01 F02 F03 F12 F13 F23, t, pad
-constexpr int kGradSlots = 4;   // LDS accumulator addresses per (wave, branch)
+constexpr int kGradSlots = 4;   // LDS accumulator addresses per (wave, branch); fewer (GradParams.nslots) on big trees
 
 struct GradParams {
     LikParams L;                // candidates as for locus_loglik_kernel (cand_pidx / cand_pfac are honoured too); L.out = lnL
@@ -295,6 +299,7 @@ struct GradParams {
     double* out_dexch;          // [items][6]   d lnL / d r  (AC, AG, AT, CG, CT, GT), branch lengths held fixed
     double* out_dlogt;          // [items][nnodes] d lnL / d log t_b, or null
     double* out_sum_dlogt;      // [items]
+    int32_t nslots;             // 4, 2 or 1: accumulator addresses per (wave, branch) that fit the LDS budget of this tree
     double* out_d2logt;         // [items][nnodes] d2 lnL / d (log t_b)^2 with everything else fixed (the diagonal of the
                                 // Hessian: preconditions the optimiser), or null
 };
@@ -320,9 +325,10 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
     extern __shared__ double lds[];
     const int nn = P.nnodes;
     double* EF = lds;                                   // [nn][kGradEF]
-    double* gb = EF + (size_t)nn * kGradEF;             // [kGradWaves][nn][kGradSlots]
-    double* hb = gb + (size_t)kGradWaves * nn * kGradSlots;                 // same shape: second derivatives
-    uint8_t* sts = (uint8_t*)(hb + (size_t)kGradWaves * nn * kGradSlots);   // [ntaxa][kGradBlock] when staged
+    const int ns = G.nslots;
+    double* gb = EF + (size_t)nn * kGradEF;             // [kGradWaves][nn][ns]
+    double* hb = gb + (size_t)kGradWaves * nn * ns;                 // same shape: second derivatives
+    uint8_t* sts = (uint8_t*)(hb + (size_t)kGradWaves * nn * ns);   // [ntaxa][kGradBlock] when staged
     __shared__ double eig[36];
     __shared__ double tipY[16 * 4];
     __shared__ double red[kGradWaves * 18];
@@ -330,8 +336,8 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double* tape = G.tape + (size_t)blockIdx.x * (size_t)(G.ntape + P.stack_depth) * 4 * kGradBlock + tid;
     double* astack = tape + (size_t)G.ntape * 4 * kGradBlock;
-    double* gbw = gb + ((size_t)wave * nn) * kGradSlots + (lane & (kGradSlots - 1));
-    double* hbw = hb + ((size_t)wave * nn) * kGradSlots + (lane & (kGradSlots - 1));
+    double* gbw = gb + ((size_t)wave * nn) * ns + (lane & (ns - 1));
+    double* hbw = hb + ((size_t)wave * nn) * ns + (lane & (ns - 1));
     const int64_t nitems = G.ncand * P.nsplit;
     for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         __syncthreads();
@@ -368,9 +374,9 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
                 }
             EF[b * kGradEF + 10] = t;
             EF[b * kGradEF + 11] = 0.0;
-            for (int w = 0; w < kGradWaves * kGradSlots; ++w) {
-                gb[((size_t)(w / kGradSlots) * nn + b) * kGradSlots + (w % kGradSlots)] = 0.0;
-                hb[((size_t)(w / kGradSlots) * nn + b) * kGradSlots + (w % kGradSlots)] = 0.0;
+            for (int w = 0; w < kGradWaves * ns; ++w) {
+                gb[((size_t)(w / ns) * nn + b) * ns + (w % ns)] = 0.0;
+                hb[((size_t)(w / ns) * nn + b) * ns + (w % ns)] = 0.0;
             }
         }
         if (tid < 64) {  // Y[mask] = U^-1 (0/1 vector of the state mask)
@@ -415,10 +421,10 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
             W[12] = fma(x[3] * f03, y[0], W[12]);     W[13] = fma(x[3] * f13, y[1], W[13]);
             W[14] = fma(x[3] * f23, y[2], W[14]);     W[15] = fma(t, d3, W[15]);
             const double c = fma(lam[3], d3, fma(lam[2], d2, fma(lam[1], d1, lam[0] * d0)));
-            atomicAdd(gbw + (size_t)node * kGradSlots, c);
+            atomicAdd(gbw + (size_t)node * ns, c);
             if (want_h) {   // d2 log L / dt^2 of this column = L''/L - (L'/L)^2; the adjoint already carries weight / L
                 const double c2 = fma(lam[3] * lam[3], d3, fma(lam[2] * lam[2], d2, fma(lam[1] * lam[1], d1, lam[0] * lam[0] * d0)));
-                atomicAdd(hbw + (size_t)node * kGradSlots, c2 - c * c * inv_seedw);
+                atomicAdd(hbw + (size_t)node * ns, c2 - c * c * inv_seedw);
             }
         };
 
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
 #pragma unroll
                     for (int i = 0; i < 4; ++i) slot[i * kGradBlock] = acc[i];   // raw: the reverse sweep redoes the rescale
                     const double mx = fmax(fmax(acc[0], acc[1]), fmax(acc[2], acc[3]));
-                    if (mx < 1e-200 && mx > 0) {
+                    if (mx < kLikRescaleBelow && mx > 0) {
                         int e;
                         frexp(mx, &e);
                         for (int i = 0; i < 4; ++i) acc[i] = ldexp(acc[i], -e);
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
                     for (int i = 0; i < 4; ++i) { a[i] = slot[i * kGradBlock]; as[i] = a[i]; }
                     double sc = 1.0;
                     const double mx = fmax(fmax(a[0], a[1]), fmax(a[2], a[3]));
-                    if (mx < 1e-200 && mx > 0) {
+                    if (mx < kLikRescaleBelow && mx > 0) {
                         int e;
                         frexp(mx, &e);
                         for (int i = 0; i < 4; ++i) as[i] = ldexp(a[i], -e);
@@ -583,12 +589,12 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
         for (int b = tid; b < nn; b += kGradBlock) {
             double g = 0;
             for (int w = 0; w < kGradWaves; ++w)
-                for (int s = 0; s < kGradSlots; ++s) g += gb[((size_t)w * nn + b) * kGradSlots + s];
+                for (int s = 0; s < ns; ++s) g += gb[((size_t)w * nn + b) * ns + s];
             const double t = EF[b * kGradEF + 10];
             if (want_h) {   // d2/d(log t)^2 = t^2 d2/dt^2 + t d/dt
                 double h = 0;
                 for (int w = 0; w < kGradWaves; ++w)
-                    for (int s = 0; s < kGradSlots; ++s) h += hb[((size_t)w * nn + b) * kGradSlots + s];
+                    for (int s = 0; s < ns; ++s) h += hb[((size_t)w * nn + b) * ns + s];
                 G.out_d2logt[item * nn + b] = t * (t * h + g);
             }
             g *= t;

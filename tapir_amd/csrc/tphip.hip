@@ -92,7 +92,7 @@ struct tphip_plan {
     // from the environment once, there): LDS bytes, whether the gradient kernel stages its state masks, resident
     // gradient blocks per CU, forced slice count (0 = automatic)
     size_t lik_lds = 0, grad_lds = 0;
-    int32_t lik_stage = 0, grad_stage = 0, grad_blocks_per_cu = 1, lik_nsplit_forced = 0;
+    int32_t lik_stage = 0, grad_stage = 0, grad_blocks_per_cu = 1, lik_nsplit_forced = 0, grad_slots = 4;
     bool lik_ok = false, grad_ok = false;
     int32_t ncat = 0;
     DevBuf<double> d_cat;     // [2 * ncat] category rates, then log weights
@@ -314,7 +314,10 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         if (p->lik_ok && p->lik_lds > 64 * 1024)
             p->lik_ok = hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
         // gradient kernel: staging helps it (95.6 -> 91.7 ms)
-        p->grad_lds = (size_t)p->nnodes * (kGradEF + 2 * kGradWaves * kGradSlots) * sizeof(double);
+        p->grad_slots = kGradSlots;   // fewer accumulator addresses per branch when the tree would not fit otherwise
+        while (p->grad_slots > 1 && (size_t)p->nnodes * (kGradEF + 2 * kGradWaves * p->grad_slots) * sizeof(double) > 100 * 1024)
+            p->grad_slots >>= 1;
+        p->grad_lds = (size_t)p->nnodes * (kGradEF + 2 * kGradWaves * p->grad_slots) * sizeof(double);
         const size_t grad_stage_bytes = (size_t)p->ntaxa * kGradBlock;
         p->grad_stage = (!getenv("TPHIP_LIK_NO_STAGE") && grad_stage_bytes <= 48 * 1024 && p->grad_lds + grad_stage_bytes <= 150 * 1024) ? 1 : 0;
         if (p->grad_stage) p->grad_lds += grad_stage_bytes;
@@ -652,7 +655,7 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
     L.cand_pfac = d_cand_pfac; L.out = d_lnl;
-    G.ntape = p->prog.ntape; G.ncand = ncand;
+    G.ntape = p->prog.ntape; G.ncand = ncand; G.nslots = p->grad_slots;
     G.out_dexch = d_dexch; G.out_dlogt = d_dlogt; G.out_sum_dlogt = d_sum_dlogt; G.out_d2logt = d_d2logt;
     if (!p->grad_ok) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-gradient kernel's LDS tables");
     const size_t lds = p->grad_lds;

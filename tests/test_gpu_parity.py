@@ -681,3 +681,33 @@ def _mixture_curve(oracle, st, pin, pi, exch, col, u, rates, weights):
     z = p.sum()
     g = (p * gk).sum() / z
     return top + np.log(z), g, (p * (hk + gk * gk)).sum() / z - g * g
+
+
+def test_locus_kernels_on_a_400_taxon_tree(oracle):
+    """Trees far beyond the bench shapes: the stage-1 kernels shrink their per-branch LDS accumulators instead of
+    refusing the tree (400 taxa: 799 nodes), rescaling of tiny partials included."""
+    engine = _engine()
+    from tapir_amd import synth
+    rng = np.random.default_rng(9)
+    ntaxa, ncols = 400, 130
+    d = synth.simulate(1, ncols, ntaxa, 123, rate_mean=0.02)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], [0, ncols], d["pi"], d["exch"], 3, [1], [[0, 1]])
+    parent = np.asarray(pin["parent"])
+    b = np.asarray(pin["blen"]) * 0.02
+    ce = np.exp(rng.normal(0, 0.3, (1, 6)))
+    val = plan.locus_loglik(st, b[None, :], [0], ce)
+    lnl, dex, dlt, sdl, d2 = plan.locus_gradient(st, b[None, :], [0], ce, curvature=True)
+    ref = oracle.locus_loglik(st, parent, b, pin["leaf"], d["pi"][0], ce[0])
+    assert abs(val[0] - ref) < 1e-9 * abs(ref) and abs(lnl[0] - ref) < 1e-9 * abs(ref)
+    h = 1e-5
+    for node in np.flatnonzero(parent >= 0)[::97]:
+        up, dn = b.copy(), b.copy()
+        up[node] *= np.exp(h)
+        dn[node] *= np.exp(-h)
+        fd = (oracle.locus_loglik(st, parent, up, pin["leaf"], d["pi"][0], ce[0]) -
+              oracle.locus_loglik(st, parent, dn, pin["leaf"], d["pi"][0], ce[0])) / (2 * h)
+        assert abs(dlt[0, node] - fd) < 2e-6 * max(1.0, np.abs(dlt).max()), (node, dlt[0, node], fd)
+    assert abs(dlt.sum() - sdl[0]) < 1e-9 * np.abs(dlt).sum() and np.all(np.isfinite(d2))
+    plan.close()
