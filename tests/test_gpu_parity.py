@@ -711,3 +711,24 @@ def test_locus_kernels_on_a_400_taxon_tree(oracle):
         assert abs(dlt[0, node] - fd) < 2e-6 * max(1.0, np.abs(dlt).max()), (node, dlt[0, node], fd)
     assert abs(dlt.sum() - sdl[0]) < 1e-9 * np.abs(dlt).sum() and np.all(np.isfinite(d2))
     plan.close()
+
+
+def test_site_rates_on_300_and_500_taxon_trees(oracle):
+    """Beyond 256 tips the site-rate kernel leaves its register-resident packed states for the byte path (NW = 0) and
+    partials need rescaling more than once per column; both against the oracle."""
+    engine = _engine()
+    from tapir_amd import synth
+    for ntaxa, ncols, seed in ((300, 96, 7), (500, 70, 8)):
+        d = synth.simulate(1, ncols, ntaxa, seed, rate_mean=0.01)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        st = d["states"].numpy()
+        plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], [0, ncols], d["pi"], d["exch"], pin["T"], [10], [[5, 15]],
+                           correction=pin["correction"])
+        got = plan.site_rates(st)
+        ref = oracle.site_rates(st, pin["parent"], pin["blen"], pin["leaf"], d["pi"][0], d["exch"][0])
+        assert np.array_equal(got["flag"], ref["flag"]) and np.array_equal(got["nres"], ref["nres"])
+        ok = (ref["flag"] == 0) | (ref["flag"] == 3)
+        assert ok.sum() > ncols // 2
+        assert _rel(got["rate"][ok], ref["rate"][ok], 1e-12).max() < RTOL_RATE
+        assert np.abs(got["lnl"] - ref["lnl"]).max() < 1e-9 * np.abs(ref["lnl"]).max()
+        plan.close()
