@@ -51,6 +51,8 @@
 #endif
 #define ORC_STEP_TOL_FIRST 1e-6 /* ... except at the first evaluation, where no second point exists yet */
 #define ORC_MAXIT 100
+#define ORC_U_CHECK 2.995732273553991 /* log(20): optima beyond this rate are confirmed by value, see maximise_column */
+#define ORC_SAT_TOL 1e-10
 #define ORC_FLAT_EPS 1e-10 /* |dlogL/du| and |d2logL/du2| below this: surface flat to fp64 -> saturated */
 
 /* ------------------------------------------------------------------------------------------------
@@ -623,24 +625,57 @@ static void column_loglik(const orc_model *m, const orc_tree *tr, const uint8_t 
  * s0 = changes / (kappa * tree length * fraction of taxa present).  (HyPhy starts at siteRate = 1, bf:1050, usually
  * e^3 away from the optimum; the maximum reached is the same, in fewer evaluations.)  Sets are 4-bit masks; a node's
  * children are joined in node order. */
-static double fitch_start(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
-                          double chrono, int resolved) {
+/* Children of every node in the order the engine's traversal joins them: deepest internal child first, tips last
+ * (Sethi-Ullman order, stable among equals -- tapir_amd/csrc/tree_program.hpp).  For binary trees the order does not
+ * matter to Fitch's pass; at a polytomy the sequential joins below depend on it, so the restatement uses the same one.
+ * Returns kids[] (concatenated, nnodes - 1 entries) and first[] (nnodes + 1 offsets); caller frees both. */
+static void fitch_child_order(const orc_tree *tr, int **kids_out, int **first_out) {
+    const int nn = tr->nnodes;
+    int *first = (int *)calloc((size_t)nn + 1, sizeof(int)), *kids = (int *)malloc(sizeof(int) * (size_t)(nn > 1 ? nn - 1 : 1));
+    int *fill = (int *)calloc((size_t)nn, sizeof(int)), *need = (int *)calloc((size_t)nn, sizeof(int));
+    for (int n = 0; n < nn; ++n) if (tr->parent[n] >= 0) ++first[tr->parent[n] + 1];
+    for (int n = 0; n < nn; ++n) first[n + 1] += first[n];
+    for (int n = 0; n < nn; ++n) if (tr->parent[n] >= 0) { int p = tr->parent[n]; kids[first[p] + fill[p]++] = n; }
+    for (int n = 0; n < nn; ++n) { /* post-order: children before parents */
+        const int a = first[n], b = first[n + 1];
+        if (a == b) continue;
+        for (int i = a + 1; i < b; ++i) { /* stable insertion sort by need, descending */
+            const int c = kids[i];
+            int j = i - 1;
+            while (j >= a && need[kids[j]] < need[c]) { kids[j + 1] = kids[j]; --j; }
+            kids[j + 1] = c;
+        }
+        int nd = 1;
+        for (int i = a; i < b; ++i) {
+            const int c = kids[i], extra = (i == a || need[c] == 0) ? 0 : 1;
+            if (need[c] + extra > nd) nd = need[c] + extra;
+        }
+        need[n] = nd;
+    }
+    free(fill); free(need);
+    *kids_out = kids; *first_out = first;
+}
+
+/* Start of the search: the rate at which the tree would carry the column's Fitch parsimony count,
+ * s0 = changes / (kappa * tree length * fraction of taxa present).  (HyPhy starts at siteRate = 1, bf:1050, usually
+ * e^3 away from the optimum; the maximum reached is the same, in fewer evaluations.)  Sets are 4-bit masks; a node's
+ * children are joined one after the other in the order of fitch_child_order. */
+static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kids, const int *first, const uint8_t *states,
+                          int64_t ncols, int64_t col, double chrono, int resolved) {
     unsigned char *set = (unsigned char *)malloc((size_t)tr->nnodes);
     int changes = 0;
-    for (int n = 0; n < tr->nnodes; ++n) {
+    for (int n = 0; n < tr->nnodes; ++n) { /* post-order: a node's children are complete when it is reached */
         if (tr->leaf_taxon[n] >= 0) {
             unsigned mask = states[(int64_t)tr->leaf_taxon[n] * ncols + col] & 15u;
             set[n] = (unsigned char)(mask ? mask : 15u);
-        } else set[n] = 0; /* no child joined yet */
-    }
-    for (int n = 0; n < tr->nnodes; ++n) { /* post-order: a node is complete before it is joined into its parent */
-        int p = tr->parent[n];
-        if (p < 0) continue;
-        if (set[p] == 0) set[p] = set[n];
-        else {
-            unsigned both = set[p] & set[n];
-            if (both) set[p] = (unsigned char)both; else { set[p] |= set[n]; ++changes; }
+            continue;
         }
+        unsigned s = 15u; /* the identity of the join: all states */
+        for (int i = first[n]; i < first[n + 1]; ++i) {
+            const unsigned x = set[kids[i]], both = s & x;
+            if (both) s = both; else { s |= x; ++changes; }
+        }
+        set[n] = (unsigned char)s;
     }
     free(set);
     const double len = m->kappa * chrono * ((double)(resolved > 0 ? resolved : 1) / (double)tr->ntaxa);
@@ -704,6 +739,14 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
             f += step * (g + step * (0.5 * h + step * (f3 / 6.0)));
             u += step;
             *flag_out = 0;
+            /* A maximum this far out may be rounding noise on the plateau log L reaches as s -> infinity (where the
+             * flatness rule fires or not depending on the last bits): confirm it by value against the largest rate. */
+            if (u >= ORC_U_CHECK) {
+                double fm, gm, hm;
+                column_loglik(m, tr, states, ncols, col, ORC_U_MAX, &fm, &gm, &hm);
+                ++*neval;
+                if (fm >= f - ORC_SAT_TOL * fmax(1.0, fabs(f))) { *flag_out = 2; u = ORC_U_MAX; f = fm; }
+            }
             break;
         }
         u_prev = u; h_prev = h; have_prev = 1;
@@ -730,6 +773,8 @@ int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, 
     }
     for (int n = 0; n < nnodes; ++n) if (parent[n] >= 0) chrono += blen[n]; /* bf:1006-1013 */
     tr.part = (double *)malloc(sizeof(double) * 12 * (size_t)nnodes);
+    int *kids = NULL, *first = NULL;
+    fitch_child_order(&tr, &kids, &first);
     for (int64_t c = 0; c < ncols; ++c) {
         unsigned uni = 0; int informative = 0, resolved = 0;
         for (int n = 0; n < nnodes; ++n) {
@@ -750,7 +795,7 @@ int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, 
             int x = (uni == 1) ? 0 : (uni == 2) ? 1 : (uni == 4) ? 2 : 3;
             s = 0.0; f = log(m.pi[x]); fl = 3;
         } else {
-            maximise_column(&m, &tr, states, ncols, c, fitch_start(&m, &tr, states, ncols, c, chrono, resolved), &s, &f, &fl, &ne);
+            maximise_column(&m, &tr, states, ncols, c, fitch_start(&m, &tr, kids, first, states, ncols, c, chrono, resolved), &s, &f, &fl, &ne);
         }
         total_eval += ne;
         rate[c] = s * m.kappa;
@@ -759,6 +804,7 @@ int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, 
         flag[c] = fl;
     }
     free(tr.part);
+    free(kids); free(first);
     return total_eval;
 }
 

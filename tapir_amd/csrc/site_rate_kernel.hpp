@@ -40,6 +40,11 @@ constexpr double kStepTol = 3e-4;       // accept when the step is this small: a
 constexpr double kStepTolFirst = 1e-6;  // ... except at the first evaluation (no second point yet)
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
+// A maximum found at a large rate may be nothing but rounding noise on the plateau log L reaches as s -> infinity (where
+// the flatness rule above fires, or not, depending on the last bits).  So an optimum at s >= kCheckRate is confirmed
+// by value: if log L at the largest rate is not lower by more than kSatTol (relative), the column is saturated.
+constexpr double kUCheck = 2.995732273553991;   // log(20)
+constexpr double kSatTol = 1e-10;
 constexpr int kSiteBlock = 64;      // one wavefront per workgroup
 constexpr int kSiteLdsHeader = 160;  // doubles of LDS before the stack: tip table [16][4] + model [32] + 2^(j/64) [64]
 #ifndef TPHIP_EXP_TABLE
@@ -484,6 +489,8 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         // start: classify_kernel left the column's parsimony-based log rate in its `rate` slot (pi_kernels.hpp)
         double u = done ? 0.0 : P.rate[col], lo = kUMin, hi = kUMax, u_prev = 0.0, h_prev = 0.0;
         bool lo_open = true, hi_open = true, have_prev = false;
+        bool checking = false;            // this evaluation is the saturation check at kUMax
+        double u_conv = 0.0, f_conv = 0.0;
         int it = 0;
         while (true) {
             double f, g, h;
@@ -493,6 +500,12 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                 ++it;
                 int flg = -1;
                 const bool uphill = !(g <= 0.0);
+                if (checking) {
+                    // value at the largest rate vs the converged optimum
+                    if (f >= f_conv - kSatTol * fmax(1.0, fabs(f_conv))) { flg = TPHIP_FLAG_SATURATED; u = kUMax; }
+                    else { flg = TPHIP_FLAG_OK; u = u_conv; f = f_conv; }
+                    checking = false;
+                } else
                 // Saturation: beyond this point g is second-order small under first-order rounding noise, its
                 // sign is meaningless; report the policy value s = 1e4 (same rule as the oracle).
                 if (fabs(g) < kFlatEps && fabs(h) < kFlatEps) { flg = TPHIP_FLAG_SATURATED; u = kUMax; }
@@ -530,6 +543,9 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                         f = fma(step, fma(step, fma(step, f3 / 6.0, 0.5 * h), g), f);
                         un = u + step;
                         flg = TPHIP_FLAG_OK;
+                        if (un >= kUCheck) {   // confirm by value before believing a maximum this far out
+                            checking = true; u_conv = un; f_conv = f; un = kUMax; flg = -1;
+                        }
                     }
                     u_prev = u; h_prev = h; have_prev = true;
                     u = un;
@@ -555,6 +571,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
 #pragma unroll
                     for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
                     u = P.rate[col]; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; have_prev = false; it = 0;
+                    checking = false;
                     done = false;
                 }
                 next += __popcll(free_mask);

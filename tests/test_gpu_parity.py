@@ -732,3 +732,20 @@ def test_site_rates_on_300_and_500_taxon_trees(oracle):
         assert _rel(got["rate"][ok], ref["rate"][ok], 1e-12).max() < RTOL_RATE
         assert np.abs(got["lnl"] - ref["lnl"]).max() < 1e-9 * np.abs(ref["lnl"]).max()
         plan.close()
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py on a fixed seed: random trees with polytomies (2..90 taxa), ragged loci, gaps / IUPAC codes,
+    noisy and saturating columns, skewed frequencies and rates -- site rates (exact flags, 1e-6 on rates, lnL) and the
+    stage-1 value / gradient kernels against the oracle.  This sweep is what exposed, and now guards, the
+    noise-dependent saturation flags (fixed by confirming far-out optima by value) and the child order of the
+    parsimony start at polytomies."""
+    _engine()
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "30", "3"], capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "30 cases, 0 with discrepancies" in p.stdout, p.stdout[-3000:]
