@@ -90,6 +90,47 @@ for case in range(ncases):
             fd = (orc.locus_loglik(st[:, sl], parent, up, leaf, pi[l], ce[c]) - orc.locus_loglik(st[:, sl], parent, dn, leaf, pi[l], ce[c])) / (2 * h)
             if abs(dlt[c, b] - fd) > 2e-5 * max(1.0, abs(fd), np.abs(dlt[c]).max()):
                 msg.append("dlogt[%d] %.8g vs fd %.8g" % (b, dlt[c, b], fd))
+    # PI tables on random rates (zeros, NaNs, tiny and huge values) with this case's loci as the column ranges
+    T = int(rng.integers(2, 60))
+    times = sorted(set(int(x) for x in rng.integers(0, T, int(rng.integers(1, 4)))))
+    ivs = []
+    for _ in range(int(rng.integers(1, 4))):
+        a = int(rng.integers(0, 80)); ivs.append([a, a + int(rng.integers(1, 60))])
+    mode = int(rng.integers(0, 2))
+    pp = engine.Plan(nt, parent, blen, leaf, off, pi, exch, T, times, ivs, correction=1.0, threshold=0, round_decimals=-1,
+                     integ_mode=mode)
+    rates = rng.gamma(0.5, 1.0, ncol) * 10 ** rng.uniform(-6, 0.5, ncol)
+    rates[rng.random(ncol) < 0.1] = 0.0
+    rates[rng.random(ncol) < 0.1] = np.nan
+    tab = pp.pi_tables(rates, None)
+    pp.close()
+    for l in range(L):
+        r = rates[off[l]:off[l + 1]]
+        fin = r[~np.isnan(r)]
+        net = orc.net_pi(fin, T) if fin.size else np.zeros(T)
+        si, se = orc.net_integrals(fin, ivs, mode) if fin.size else (np.zeros(len(ivs)), np.zeros(len(ivs)))
+        want = np.concatenate([net, net[times], si])
+        gotrow = tab[l][:T + len(times) + len(ivs)]
+        err = np.abs(gotrow - want) / np.maximum(np.abs(want), 1e-300)
+        err = np.where(np.abs(want) < 1e-300, np.abs(gotrow), err)
+        if err.size and err.max() > 1e-9:
+            msg.append("PI table locus %d rel %.2e at %d (T %d, times %s, ivs %s, mode %d)" % (l, err.max(), int(err.argmax()), T, times, ivs, mode))
+    # rate mixture (opt-in extension) on the first locus
+    if off[1] > off[0] and case % 3 == 0:
+        K = int(rng.integers(2, 6))
+        cr = np.exp(rng.normal(0, 0.7, K)); cw = rng.dirichlet(np.ones(K))
+        pm = engine.Plan(nt, parent, blen, leaf, off[:2], pi[:1], exch[:1], 5, [1], [[0, 2]], cat_rates=cr, cat_weights=cw)
+        gm = pm.site_rates(st[:, :off[1]])
+        pm.close()
+        rm = orc.site_rates(st[:, :off[1]], parent, blen, leaf, pi[0], exch[0], cr, cw)
+        if not np.array_equal(gm["flag"], rm["flag"]):
+            msg.append("mixture flags differ at %s" % np.flatnonzero(gm["flag"] != rm["flag"])[:4])
+        else:
+            okm = (rm["flag"] == 0) | (rm["flag"] == 3)
+            relm = np.abs(gm["rate"][okm] - rm["rate"][okm]) / np.maximum(np.abs(rm["rate"][okm]), 1e-12)
+            dlm = np.abs(gm["lnl"] - rm["lnl"])
+            if relm.size and relm.max() > 1e-6 and dlm[okm][relm > 1e-6].max() > 1e-9:
+                msg.append("mixture rate rel %.2e" % relm.max())
     plan.close()
     if msg:
         bad += 1
