@@ -33,32 +33,76 @@ def read_matrix(path):
     m = re.search(r"\bmatrix\b(.*?);", text_nc, flags=re.I | re.S)
     if not m:
         raise NexusError("%s has no MATRIX block" % path)
-    names, seqs = [], {}
-    for line in m.group(1).splitlines():
-        line = line.strip()
-        if not line:
-            continue
-        if line[0] in "'\"":
-            q = line[0]
-            end = line.index(q, 1)
-            name, rest = line[1:end], line[end + 1:]
-        else:
-            parts = line.split(None, 1)
-            name, rest = parts[0], (parts[1] if len(parts) > 1 else "")
-        if name not in seqs:
-            names.append(name)
-            seqs[name] = []
-        seqs[name].append(re.sub(r"\s+", "", rest))
-    rows = ["".join(seqs[n]) for n in names]
+    dm = re.search(r"dimensions\s+[^;]*?nchar\s*=\s*(\d+)", text_nc, flags=re.I)
+    nchar = int(dm.group(1)) if dm else None
+    fm = re.search(r"\bformat\b([^;]*);", text_nc, flags=re.I | re.S)
+    fmt = fm.group(1) if fm else ""
+    interleaved = re.search(r"\binterleave(\s*=\s*yes)?\b", fmt, flags=re.I) is not None and \
+        re.search(r"\binterleave\s*=\s*no\b", fmt, flags=re.I) is None
+    names, rows = _matrix_by_lines(m.group(1))
     if not rows:
         raise NexusError("%s has an empty MATRIX block" % path)
+    if nchar is not None and not interleaved and any(len(r) != nchar for r in rows):
+        # a sequential (non-interleaved) matrix may wrap a sequence over several lines: read it as a token stream
+        names, rows = _matrix_by_tokens(m.group(1), nchar)
     n = len(rows[0])
     for name, r in zip(names, rows):
         if len(r) != n:  # tapir/compute.py:103 asserts equal lengths
             raise NexusError("sequence %s has %d characters, expected %d" % (name, len(r), n))
-    dm = re.search(r"dimensions\s+[^;]*?nchar\s*=\s*(\d+)", text_nc, flags=re.I)
-    if dm and int(dm.group(1)) != n:
-        raise NexusError("%s: nchar=%s but sequences have %d characters" % (path, dm.group(1), n))
+    if nchar is not None and nchar != n:
+        raise NexusError("%s: nchar=%s but sequences have %d characters" % (path, nchar, n))
+    mc = re.search(r"matchchar\s*=\s*(\S)", fmt, flags=re.I)
+    if mc:  # MATCHCHAR: "same state as the first sequence at this position"
+        ch = mc.group(1)
+        first = rows[0]
+        rows = [first] + ["".join(f if c == ch else c for c, f in zip(r, first)) for r in rows[1:]]
+    return names, rows
+
+
+def _split_label(line):
+    if line[0] in "'\"":
+        q = line[0]
+        end = line.index(q, 1)
+        return line[1:end], line[end + 1:]
+    parts = line.split(None, 1)
+    return parts[0], (parts[1] if len(parts) > 1 else "")
+
+
+def _matrix_by_lines(block):
+    """One `label sequence-chunk` per line; a label that comes back continues its sequence (interleaved blocks)."""
+    names, seqs = [], {}
+    for line in block.splitlines():
+        line = line.strip()
+        if not line:
+            continue
+        name, rest = _split_label(line)
+        if name not in seqs:
+            names.append(name)
+            seqs[name] = []
+        seqs[name].append(re.sub(r"\s+", "", rest))
+    return names, ["".join(seqs[n]) for n in names]
+
+
+def _matrix_by_tokens(block, nchar):
+    """Sequential format: a label, then characters (over as many lines and blanks as it takes) until nchar are read."""
+    names, rows = [], []
+    text = block.strip()
+    pos = 0
+    while pos < len(text):
+        while pos < len(text) and text[pos].isspace():
+            pos += 1
+        if pos >= len(text):
+            break
+        name, rest = _split_label(text[pos:])
+        pos = len(text) - len(rest)
+        chars = []
+        while len(chars) < nchar and pos < len(text):
+            c = text[pos]
+            pos += 1
+            if not c.isspace():
+                chars.append(c)
+        names.append(name)
+        rows.append("".join(chars))
     return names, rows
 
 

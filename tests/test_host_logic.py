@@ -601,3 +601,19 @@ def test_stage1_blocks_of_loci_give_the_same_rates():
     a = pipeline.model_averaged_exchangeabilities(*args)
     b = pipeline.model_averaged_exchangeabilities(*args, block_loci=2)
     assert a.shape == (3, 6) and np.max(np.abs(a - b) / a) < 1e-6
+
+
+def test_nexus_sequential_wrapping_and_matchchar(tmp_path):
+    """NEXUS variants DendroPy reads and HyPhy's ReadDataFile accepts: a sequential matrix whose sequences wrap over
+    several lines (label on its own line or not), and MATCHCHAR."""
+    from tapir_amd import nexus
+    p = tmp_path / "w.nex"
+    p.write_text("#NEXUS\nBEGIN DATA;\nDIMENSIONS NTAX=2 NCHAR=8;\nFORMAT DATATYPE=DNA;\nMATRIX\n'tax a'\n ACG T\n ACGT\nb\nACGTAC\nGT\n;\nEND;\n")
+    names, st = nexus.read_states(str(p))
+    assert names == ["tax a", "b"] and st.tolist() == [[1, 2, 4, 8, 1, 2, 4, 8]] * 2
+    p.write_text("#NEXUS\nBEGIN DATA;\nDIMENSIONS NTAX=2 NCHAR=4;\nFORMAT DATATYPE=DNA MATCHCHAR=.;\nMATRIX\na ACGT\nb ..C.\n;\nEND;\n")
+    names, st = nexus.read_states(str(p))
+    assert st.tolist() == [[1, 2, 4, 8], [1, 2, 2, 8]]
+    p.write_text("#NEXUS\nBEGIN DATA;\nDIMENSIONS NTAX=2 NCHAR=4;\nFORMAT DATATYPE=DNA;\nMATRIX\na ACGT\nb ACG\n;\nEND;\n")
+    with pytest.raises(nexus.NexusError):
+        nexus.read_states(str(p))
