@@ -37,6 +37,8 @@ constexpr double kUMin = -23.025850929940457;  // log(1e-10)
 constexpr double kUMax = 9.210340371976184;    // log(1e4)
 constexpr double kStepMax = 2.0;
 constexpr double kStepTol = 3e-4;       // accept when the step is this small: applied with a third-order correction
+constexpr double kHermiteSpan = 2e-4;   // ... while |step| * |distance between the two points| stays below this
+constexpr double kHermiteTol = 2e-3;    // final step from the two-point Hermite model of f' accepted below this size
 constexpr double kStepTolFirst = 1e-6;  // ... except at the first evaluation (no second point yet)
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
 #pragma unroll
         for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
         // start: classify_kernel left the column's parsimony-based log rate in its `rate` slot (pi_kernels.hpp)
-        double u = done ? 0.0 : P.rate[col], lo = kUMin, hi = kUMax, u_prev = 0.0, h_prev = 0.0;
+        double u = done ? 0.0 : P.rate[col], lo = kUMin, hi = kUMax, u_prev = 0.0, h_prev = 0.0, g_prev = 0.0;
         bool lo_open = true, hi_open = true, have_prev = false;
         bool checking = false;            // this evaluation is the saturation check at kUMax
         double u_conv = 0.0, f_conv = 0.0;
@@ -513,6 +515,32 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                 else if (u <= kUMin && !uphill) { flg = TPHIP_FLAG_ZERO; }
                 else {
                     if (uphill) { lo = u; lo_open = false; } else { hi = u; hi_open = false; }
+                    // Two evaluations in hand: the cubic Hermite interpolant of f' through (u_prev, g_prev, h_prev) and
+                    // (u, g, h) locates the zero to fourth order, so a remaining step below kHermiteTol is taken without
+                    // evaluating again (same rule as the oracle).
+                    bool hermite = false;
+                    double un = u;
+                    if (have_prev && h < 0.0) {
+                        const double d = u - u_prev;
+                        const double id = 1.0 / d;
+                        const double c3 = (2.0 * (g_prev - g) * id + (h + h_prev)) * id * id;
+                        const double c2 = (h - h_prev) * (0.5 * id) + 1.5 * c3 * d;
+                        double t = -g / h;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const double p = fma(t, fma(t, fma(t, c3, c2), h), g);
+                            const double dp = fma(t, fma(3.0 * t, c3, 2.0 * c2), h);
+                            t = (dp < 0.0) ? t - p / dp : t;
+                        }
+                        if (fabs(t) < kHermiteTol && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < kHermiteSpan) {
+                            f = fma(t, fma(t, fma(t, fma(t, 0.25 * c3, c2 * (1.0 / 3.0)), 0.5 * h), g), f);
+                            un = u + t;
+                            hermite = true;
+                            flg = TPHIP_FLAG_OK;
+                            if (un >= kUCheck) { checking = true; u_conv = un; f_conv = f; un = kUMax; flg = -1; }
+                        }
+                    }
+                    if (!hermite) {
                     // Concave: Newton's -g/h refined to log(1 - g/h), the exact maximiser of m u - a exp(u) + c
                     // fitted to (g, h) (same rule as the oracle); convex: a capped step uphill.
                     double step;
@@ -525,7 +553,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     if (!(step <= kStepMax)) step = kStepMax;
                     if (step < -kStepMax) step = -kStepMax;
                     const double tol = have_prev ? kStepTol : kStepTolFirst;
-                    double un = u + step;
+                    un = u + step;
                     // the bracket safeguard must not see a converged (possibly underflowing) step
                     if (fabs(step) >= tol) {
                         if (un >= hi) un = hi_open ? kUMax : 0.5 * (lo + hi);
@@ -547,7 +575,8 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                             checking = true; u_conv = un; f_conv = f; un = kUMax; flg = -1;
                         }
                     }
-                    u_prev = u; h_prev = h; have_prev = true;
+                    }
+                    u_prev = u; h_prev = h; g_prev = g; have_prev = true;
                     u = un;
                     if (flg < 0 && it >= kMaxIt) flg = TPHIP_FLAG_MAXIT;
                 }
