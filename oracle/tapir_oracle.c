@@ -38,6 +38,7 @@
  *   branch above node n (ignored for the root), already divided by the correction factor.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -55,7 +56,7 @@
 #define ORC_SAT_TOL 1e-10
 #ifndef ORC_HERMITE_TOL /* 0 switches the rule off (accuracy experiments against a tight reference) */
 #define ORC_HERMITE_SPAN 2e-4 /* ... and only while |step| * |distance between the two points| stays below this */
-#define ORC_HERMITE_TOL 2e-3 /* final step from the two-point Hermite model of f' accepted below this size */
+#define ORC_HERMITE_TOL 1e-3 /* final step from the two-point Hermite model of f' accepted below this size */
 #else
 #define ORC_HERMITE_SPAN 2e-4
 #endif
@@ -685,7 +686,13 @@ static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kid
     }
     free(set);
     const double len = m->kappa * chrono * ((double)(resolved > 0 ? resolved : 1) / (double)tr->ntaxa);
-    double u0 = (len > 0) ? log((double)(changes > 0 ? changes : 1) / len) : 0.0;
+    /* parsimony undercounts where changes are dense: stretch the count with p = changes per branch among the taxa
+     * present, m' = B (-a ln(1 - p/a)), a = 0.30, p capped at 0.28 (same constants as classify_kernel) */
+    double mch = (double)(changes > 0 ? changes : 1);
+    const double B = (double)(2 * resolved - 3 > 1 ? 2 * resolved - 3 : 1);
+    const double pden = fmin(mch / B, 0.28);
+    mch = B * (-0.30 * log(1.0 - pden / 0.30));
+    double u0 = (len > 0) ? log(mch / len) : 0.0;
     if (!(u0 == u0)) u0 = 0.0;
     if (u0 < -20.0) u0 = -20.0;
     if (u0 > 8.0) u0 = 8.0;
@@ -702,6 +709,9 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
     for (int it = 0; it < ORC_MAXIT; ++it) {
         column_loglik(m, tr, states, ncols, col, u, &f, &g, &h);
         ++*neval;
+#ifdef ORC_TRACE
+        fprintf(stderr, "  eval %d: u %.12f f %.12f g %.6e h %.6e\n", it, u, f, g, h);
+#endif
         int uphill = !(g <= 0); /* NaN (L underflowed to 0 at tiny s) counts as uphill */
         /* Saturation: log L has reached its s -> infinity asymptote to within fp64 resolution.  Beyond this
          * point g is a second-order-small number buried under first-order rounding noise (its sign is
@@ -738,7 +748,10 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
                 if (dp < 0) t -= p / dp;
             }
             /* the interpolation error grows like (d t)^2: a far-away first point must not vouch for the step */
-            if (fabs(t) < ORC_HERMITE_TOL && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < ORC_HERMITE_SPAN) {
+            /* ... and where the curvature is weak compared with the higher-order terms (a nearly flat column) the zero
+             * of f' is too sensitive to the model: the quadratic and cubic terms must be a small correction of h */
+            if (fabs(t) < ORC_HERMITE_TOL && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < ORC_HERMITE_SPAN &&
+                fabs(t * (c2 + t * c3)) < 0.02 * fabs(h)) {
                 f += t * (g + t * (0.5 * h + t * (c2 / 3.0 + t * (c3 / 4.0))));
                 u += t;
                 *flag_out = 0;
@@ -759,16 +772,18 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
             else if (un <= lo) un = lo_open ? ORC_U_MIN : 0.5 * (lo + hi);
             step = un - u;
         }
-        if (fabs(step) < tol) {
-            /* Converged.  Rather than spend one more evaluation to watch the step shrink from ~1e-4 to ~1e-8,
-             * the last step gets its third-order correction: the third derivative f3 from the two most recent
-             * curvatures (the step's own model already carries f3 = h), leaving an error of O(step^3), i.e.
-             * ~1e-8 or less in u. */
-            double f3 = h;
-            if (have_prev && h < 0) {
-                f3 = (h - h_prev) / (u - u_prev);
-                step -= 0.5 * ((f3 - h) / h) * step * step;
-            }
+        /* Converged?  Rather than spend one more evaluation to watch the step shrink from ~1e-4 to ~1e-8, the last
+         * step gets its third-order correction: the third derivative f3 from the two most recent curvatures (the
+         * step's own model already carries f3 = h), leaving an error of O(step^3), i.e. ~1e-8 or less in u.  Where that
+         * correction is a sizeable part of the step itself (weak curvature, far previous point) the model behind it is
+         * not good enough to stop on: iterate once more unless the step is already negligible. */
+        double f3 = h, corr = 0.0;
+        if (have_prev && h < 0) {
+            f3 = (h - h_prev) / (u - u_prev);
+            corr = 0.5 * ((f3 - h) / h) * step * step;
+        }
+        if (fabs(step) < tol && (fabs(corr) <= 0.05 * fabs(step) || fabs(step) < ORC_STEP_TOL_FIRST)) {
+            step -= corr;
             f += step * (g + step * (0.5 * h + step * (f3 / 6.0)));
             u += step;
             *flag_out = 0;

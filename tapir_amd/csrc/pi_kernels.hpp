@@ -71,13 +71,22 @@ struct ColumnScan {
     }
 };
 
+constexpr double kStartA = 0.30, kStartDensityCap = 0.28;
+
 // Where the optimiser starts for a column that needs it: the rate at which the tree would carry the column's
 // parsimony count, s0 = changes / (kappa * tree length * fraction of taxa present).  HyPhy starts every column at
 // siteRate = 1 (bf:1050), typically e^3 away from the optimum; from s0 (median error 10 %) the same maximum is reached in
 // 2.8 instead of 4.4 evaluations on the C3 shape.  Passed to site_rate_kernel through the column's `rate` slot.
 __device__ __forceinline__ double start_log_rate(const ClassifyParams& P, const LocusModel* __restrict__ M, const ColumnScan& c) {
     const double len = M->kappa * P.chrono_length * ((double)(c.resolved > 0 ? c.resolved : 1) / (double)P.ntaxa);
-    const double m = (double)(c.changes > 0u ? c.changes : 1u);
+    double m = (double)(c.changes > 0u ? c.changes : 1u);
+    // parsimony undercounts where changes are dense: with p = changes per branch among the taxa present, the count is
+    // stretched to B * (-a ln(1 - p/a)), a = 0.30 (the shape of a multiple-hit correction; a calibrated on the
+    // synthetic shapes, where it centres the start on the optimum for p up to 0.28 and saves another 6-12 % of the
+    // evaluations; only the starting point depends on it)
+    const double B = (double)(2 * c.resolved - 3 > 1 ? 2 * c.resolved - 3 : 1);
+    const double pden = fmin(m / B, kStartDensityCap);
+    m = B * (-kStartA * log(1.0 - pden / kStartA));
     double u0 = (len > 0.0) ? log(m / len) : 0.0;
     u0 = (u0 == u0) ? u0 : 0.0;
     return fmin(fmax(u0, -20.0), 8.0);

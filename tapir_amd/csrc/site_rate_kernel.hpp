@@ -38,7 +38,7 @@ constexpr double kUMax = 9.210340371976184;    // log(1e4)
 constexpr double kStepMax = 2.0;
 constexpr double kStepTol = 3e-4;       // accept when the step is this small: applied with a third-order correction
 constexpr double kHermiteSpan = 2e-4;   // ... while |step| * |distance between the two points| stays below this
-constexpr double kHermiteTol = 2e-3;    // final step from the two-point Hermite model of f' accepted below this size
+constexpr double kHermiteTol = 1e-3;    // final step from the two-point Hermite model of f' accepted below this size
 constexpr double kStepTolFirst = 1e-6;  // ... except at the first evaluation (no second point yet)
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
@@ -532,7 +532,10 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                             const double dp = fma(t, fma(3.0 * t, c3, 2.0 * c2), h);
                             t = (dp < 0.0) ? t - p / dp : t;
                         }
-                        if (fabs(t) < kHermiteTol && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < kHermiteSpan) {
+                        // (span bound: the interpolation error grows like (d t)^2; last condition: on a nearly flat column
+                        // the zero of f' is too sensitive to the model unless the higher-order terms are a small part of h)
+                        if (fabs(t) < kHermiteTol && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < kHermiteSpan &&
+                            fabs(t * fma(t, c3, c2)) < 0.02 * fabs(h)) {
                             f = fma(t, fma(t, fma(t, fma(t, 0.25 * c3, c2 * (1.0 / 3.0)), 0.5 * h), g), f);
                             un = u + t;
                             hermite = true;
@@ -560,14 +563,17 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                         else if (un <= lo) un = lo_open ? kUMin : 0.5 * (lo + hi);
                         step = un - u;
                     }
-                    if (fabs(step) < tol) {
-                        // Converged: the last step gets its third-order correction (third derivative f3 from the two
-                        // most recent curvatures) instead of one more evaluation -- same rule as the oracle.
-                        double f3 = h;
-                        if (have_prev && h < 0.0) {
-                            f3 = (h - h_prev) / (u - u_prev);
-                            step -= 0.5 * ((f3 - h) / h) * step * step;
-                        }
+                    // Converged: the last step gets its third-order correction (third derivative f3 from the two most
+                    // recent curvatures) instead of one more evaluation -- same rule as the oracle.  Where that
+                    // correction is a sizeable part of the step itself (weak curvature, far previous point) the model
+                    // behind it is not good enough to stop on: iterate once more unless the step is already negligible.
+                    double f3 = h, corr = 0.0;
+                    if (have_prev && h < 0.0) {
+                        f3 = (h - h_prev) / (u - u_prev);
+                        corr = 0.5 * ((f3 - h) / h) * step * step;
+                    }
+                    if (fabs(step) < tol && (fabs(corr) <= 0.05 * fabs(step) || fabs(step) < kStepTolFirst)) {
+                        step -= corr;
                         f = fma(step, fma(step, fma(step, f3 / 6.0, 0.5 * h), g), f);
                         un = u + step;
                         flg = TPHIP_FLAG_OK;
