@@ -34,6 +34,7 @@ RATE_ORDER = ("AC", "AG", "AT", "CG", "CT", "GT")
 LOG_RATE_MIN, LOG_RATE_MAX = -7.0, 9.2      # exchangeabilities within [9e-4, 1e4]
 LOG_BLEN_MIN, LOG_BLEN_MAX = -23.0, 4.0     # branch lengths within [1e-10, 55]
 MAX_LOG_STEP = 2.0                          # largest move of a log-parameter in one iteration
+ESCAPE_RATE = 0.05                          # where a wrongly collapsed exchangeability is put back (Stage1._sub_escape)
 ESCAPE_LENGTH = 1e-3                        # where a wrongly collapsed branch is put back (Stage1._grm_escape)
 PRUNE_NATS = 30.0                           # see Stage1.fit_submodels
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
@@ -367,8 +368,27 @@ class Stage1:
         kick = (b < 1e-6) & (slope * ESCAPE_LENGTH < -1e-7 * np.reshape(fscale, (-1, 1)))
         kick &= self._kicks[idx][:, None] < 3                # a branch that keeps coming back really is zero
         Xn[:, 5:] = np.where(kick, np.log(ESCAPE_LENGTH), logb)
-        moved = kick.any(axis=1)
+        # the five rates: same test at their lower bound (see _sub_escape)
+        rslope = G[:, :5] / np.exp(X[:, :5])
+        rkick = (X[:, :5] < LOG_RATE_MIN + 1.0) & (rslope * ESCAPE_RATE < -1e-7 * np.reshape(fscale, (-1, 1)))
+        rkick &= self._kicks[idx][:, None] < 3
+        Xn[:, :5] = np.where(rkick, np.log(ESCAPE_RATE), X[:, :5])
+        moved = kick.any(axis=1) | rkick.any(axis=1)
         self._kicks[idx] += moved
+        return Xn, moved
+
+    def _sub_escape(self, idx, X, G):
+        """The same trap for a rate class that sits at its lower bound (typically because the general model put that
+        rate there and the class starts from it): if the likelihood rises with the rate itself, d f / d r < 0, the
+        point is an artefact of the log scale, not a boundary optimum; put the rate at ESCAPE_RATE and carry on."""
+        r = np.exp(X)
+        slope = G / r                                        # d(-lnL) / d r
+        fscale = 1.0 + np.abs(self._sub_last_f[idx])
+        kick = (X < LOG_RATE_MIN + 1.0) & self._sub_active[idx] & (slope * ESCAPE_RATE < -1e-7 * fscale[:, None])
+        kick &= self._sub_kicks[idx][:, None] < 2
+        Xn = np.where(kick, np.log(ESCAPE_RATE), X)
+        moved = kick.any(axis=1)
+        self._sub_kicks[idx] += moved
         return Xn, moved
 
     def initial_branch_lengths(self):
@@ -434,6 +454,7 @@ class Stage1:
             g = np.zeros((n, D))
             for c in range(D):
                 g[:, c] = (dr * (cls == c)).sum(1)
+            self._sub_last_f[idx] = -lnl
             return -lnl, -np.where(self._sub_active[idx], g, 0.0)
         # central differences: the stencil's exchangeabilities are the base point's times precomputed factors
         # (member rates of class j times e^{+-h}), so a whole iteration's candidates are two broadcasts
@@ -448,6 +469,7 @@ class Stage1:
         f[need] = -self._lik(self._stash, loc[need], exch[need], loc[need], scale[need])
         f = f.reshape(n, per)
         g = (f[:, 1::2] - f[:, 2::2]) / (2 * self.h)
+        self._sub_last_f[idx] = f[:, 0]
         return f[:, 0], np.where(self._sub_active[idx], g, 0.0)
 
     def fit_submodels(self, grm_exch, grm_t, maxit=100, grm_lnl=None):
@@ -496,8 +518,10 @@ class Stage1:
             self.pruned += int(drop.sum())
             return drop
 
+        self._sub_last_f = np.zeros(L * M)
+        self._sub_kicks = np.zeros(L * M, dtype=np.int64)
         opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0, active=self._sub_active, maxit=maxit,
-                     lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune if self.prune_models else None)
+                     lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune if self.prune_models else None, escape=self._sub_escape)
         x, f = opt.run()
         self.sub_iters = opt.iters
         exch = self._sub_exch(x, self._sub_cls).reshape(L, M, 6)
