@@ -141,6 +141,15 @@ for case in range(ncases):
             dlm = np.abs(gm["lnl"] - rm["lnl"])
             if relm.size and relm.max() > 1e-6 and dlm[okm][relm > 1e-6].max() > 1e-9:
                 msg.append("mixture rate rel %.2e" % relm.max())
+    # site-pattern compression against numpy
+    pst, poff, pw, cmap = engine.compress_columns(st, off)
+    norm = np.where(st == 0, 15, st & 15)
+    if pw.sum() != ncol or not np.array_equal(pst[:, cmap], norm):
+        msg.append("compress_columns: map does not reproduce the columns")
+    for l in range(L):
+        uniq = np.unique(norm[:, off[l]:off[l + 1]], axis=1).shape[1] if off[l + 1] > off[l] else 0
+        if poff[l + 1] - poff[l] != uniq:
+            msg.append("compress_columns: locus %d has %d patterns, numpy finds %d" % (l, poff[l + 1] - poff[l], uniq))
     plan.close()
     if msg:
         bad += 1
