@@ -749,3 +749,51 @@ def test_randomised_parity_sweep():
                        timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "30 cases, 0 with discrepancies" in p.stdout, p.stdout[-3000:]
+
+
+def test_cli_site_rates_and_subset_paths_on_gpu(golden_dir, tmp_path, oracle):
+    """The two re-analysis paths of the command line through the real engine: --site-rates (PI kernels alone on the
+    rates of existing .rates files: divided by the correction again and NOT culled, as bin/tapir_compute.py:103-104,
+    153-158 does) and --subset-pi-map-file (rates sliced before PI, tapir/base.py:116-123)."""
+    _engine()
+    import json
+    import os
+    import shutil
+    import sqlite3
+    from test_host_logic import _run_cli
+    from tapir_amd import cli, nexus
+    outdir, _ = _run_cli(golden_dir, tmp_path)
+    rates_dir = tmp_path / "rates"
+    rates_dir.mkdir()
+    shutil.copy(os.path.join(outdir, "chr1_918.nex.rates"), rates_dir)
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    cli.main([str(rates_dir), os.path.join(golden_dir, "Euteleost.tree"), "--output", str(out2), "--times", "10,50",
+              "--intervals", "0-10,20-70", "--site-rates"])
+    conn = sqlite3.connect(os.path.join(str(out2), "phylogenetic-informativeness.sqlite"))
+    assert conn.execute("select locus from loci").fetchall() == [("chr1_918.nex",)]
+    doc = json.load(open(rates_dir / "chr1_918.nex.rates"))
+    r = np.array([x["rate"] for x in doc["sites"]["rates"]]) / 100
+    for t in (10, 50):
+        got = conn.execute("select pi from net where time=?", (t,)).fetchone()[0]
+        assert abs(got - np.nansum(oracle.get_townsend_pi(t, r))) <= 1e-9 * got
+    si, _ = oracle.net_integrals(r, [[0, 10], [20, 70]], 0)
+    rows = dict(conn.execute("select interval, pi from interval").fetchall())
+    assert abs(rows["0-10"] - si[0]) <= 1e-9 * si[0] and abs(rows["20-70"] - si[1]) <= 1e-9 * si[1]
+    conn.close()
+    # subset map
+    m = tmp_path / "map.tsv"
+    m.write_text("chr1_918.nex\t50\t150\n")
+    sub = tmp_path / "sub"
+    sub.mkdir()
+    outdir3, _ = _run_cli(golden_dir, sub, extra=["--subset-pi-map-file", str(m)])
+    doc = json.load(open(os.path.join(outdir3, "chr1_918.nex.rates")))
+    _, st = nexus.read_states(os.path.join(golden_dir, "chr1_918.nex"))
+    inf = ((st == 1) | (st == 2) | (st == 4) | (st == 8)).sum(axis=0) >= 3
+    rr = np.array([x["rate"] for x in doc["sites"]["corrected_rates"]])
+    rr[~inf] = np.nan
+    rr = rr[50:150]
+    conn = sqlite3.connect(os.path.join(outdir3, "phylogenetic-informativeness.sqlite"))
+    net20 = conn.execute("select pi from net where time=20").fetchone()[0]
+    assert abs(net20 - np.nansum(oracle.get_townsend_pi(20, rr))) <= 1e-9 * net20
+    conn.close()
