@@ -86,15 +86,36 @@ struct Partial {  // value and first/second derivative (wrt u) of the 4 conditio
     double v[4], d1[4], d2[4];
 };
 
-// acc *= m (product rule for value / first / second derivative)
+// In-place FP64 updates through one-instruction asm statements whose "+v" operand ties result and accumulator to the
+// same register.  Written in plain C++ the accumulator's new values land in fresh registers (v_fmac writes its
+// addend, which is a temporary) and every arm of the op switch ends in 8-14 v_mov_b64 copies back into the registers
+// the loop carries (7 % of the VALU instructions of an evaluation).  FP64 VALU -> VALU dependencies are
+// interlocked in hardware, so the statements need no padding (cdna_hip_programming.md section 5.7 item 2).
+__device__ __forceinline__ void mul_into(double& acc, double b) {          // acc *= b
+    asm("v_mul_f64 %0, %0, %1" : "+v"(acc) : "v"(b));
+}
+__device__ __forceinline__ void fma_into(double& acc, double a, double b) {  // acc += a * b
+    asm("v_fmac_f64 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+// dst = a * b + c where dst's previous value is dead: the "+v" only pins the result to dst's register.
+__device__ __forceinline__ void fma_over(double& dst, double a, double b, double c) {
+    asm("v_fma_f64 %0, %1, %2, %3" : "+v"(dst) : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void mul_over(double& dst, double a, double b) {
+    asm("v_mul_f64 %0, %1, %2" : "+v"(dst) : "v"(a), "v"(b));
+}
+
+// acc *= m (product rule for value / first / second derivative), every component updated in its own register
 __device__ __forceinline__ void partial_mul(Partial& a, const Partial& m) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        double a0 = a.v[i], a1 = a.d1[i], a2 = a.d2[i];
-        double t = a1 * m.d1[i];
-        a.d2[i] = fma(a2, m.v[i], fma(a0, m.d2[i], t + t));
-        a.d1[i] = fma(a1, m.v[i], a0 * m.d1[i]);
-        a.v[i] = a0 * m.v[i];
+        const double twice = a.d1[i] + a.d1[i];
+        mul_into(a.d2[i], m.v[i]);
+        fma_into(a.d2[i], a.v[i], m.d2[i]);
+        fma_into(a.d2[i], twice, m.d1[i]);
+        mul_into(a.d1[i], m.v[i]);
+        fma_into(a.d1[i], a.v[i], m.d1[i]);
+        mul_into(a.v[i], m.v[i]);
     }
 }
 
@@ -140,6 +161,33 @@ __device__ __forceinline__ void tip_message(const ModelRegs& R, const double* __
     }
 }
 
+// the same message written over `acc` (TIP_SET: the accumulator's previous content is dead), results pinned to the
+// registers the loop carries
+__device__ __forceinline__ void tip_message_over(const ModelRegs& R, const double* __restrict__ etab, const double* w, double ts, Partial& acc) {
+    double a[3], b[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double x = R.lam[k] * ts;
+        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
+        a[k] = e * w[k + 1];
+        b[k] = x * a[k];
+        c[k] = fma(x, b[k], b[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double* Ur = R.U + i * 3;
+        fma_over(acc.v[i], Ur[0], a[0], w[0]);
+        fma_into(acc.v[i], Ur[1], a[1]);
+        fma_into(acc.v[i], Ur[2], a[2]);
+        mul_over(acc.d1[i], Ur[0], b[0]);
+        fma_into(acc.d1[i], Ur[1], b[1]);
+        fma_into(acc.d1[i], Ur[2], b[2]);
+        mul_over(acc.d2[i], Ur[0], c[0]);
+        fma_into(acc.d2[i], Ur[1], c[1]);
+        fma_into(acc.d2[i], Ur[2], c[2]);
+    }
+}
+
 // acc <- P(t s) * acc with derivatives (internal branch)
 __device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* __restrict__ etab, double ts, double f, Partial& p) {
     double w0[4], w1[4], w2[4];
@@ -167,9 +215,15 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* _
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double* Ur = R.U + i * 3;
-        p.v[i] = fma(Ur[2], a[2], fma(Ur[1], a[1], fma(Ur[0], a[0], z0)));
-        p.d1[i] = fma(Ur[2], b[2], fma(Ur[1], b[1], fma(Ur[0], b[0], z1)));
-        p.d2[i] = fma(Ur[2], c[2], fma(Ur[1], c[1], fma(Ur[0], c[0], z2)));
+        fma_over(p.v[i], Ur[0], a[0], z0);   // p's previous content was consumed by the w's above
+        fma_into(p.v[i], Ur[1], a[1]);
+        fma_into(p.v[i], Ur[2], a[2]);
+        fma_over(p.d1[i], Ur[0], b[0], z1);
+        fma_into(p.d1[i], Ur[1], b[1]);
+        fma_into(p.d1[i], Ur[2], b[2]);
+        fma_over(p.d2[i], Ur[0], c[0], z2);
+        fma_into(p.d2[i], Ur[1], c[1]);
+        fma_into(p.d2[i], Ur[2], c[2]);
     }
 }
 
@@ -292,48 +346,51 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
         if constexpr (NW == 0) {
             if (nxt.code <= OP_TIP_MUL) st_nxt = load_state(P, nxt.taxon, col);
         }
-        if (op.code != OP_BRANCH && op.code != OP_PUSH) {
-            // acc *= m, with m the message of a tip (TIP_SET / TIP_MUL) or a parked sibling (POP_MUL).
-            // TIP_SET is TIP_MUL onto the identity: acc is the identity at program start and after every PUSH,
-            // which are the only places a subtree can begin (tree_program.hpp).
-            Partial m;
-            if (op.code == OP_POP_MUL) {
-                --sp;
-                const double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    m.v[i] = slot[(i)*kSiteBlock];
-                    m.d1[i] = slot[(4 + i) * kSiteBlock];
-                    m.d2[i] = slot[(8 + i) * kSiteBlock];
-                }
+        if (op.code <= OP_TIP_MUL) {
+            unsigned mask;
+            if constexpr (NW > 0) {
+                if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
+                mask = cur & 15u;   // zero codes were turned into 15 when the word was packed
+                cur >>= 4;
+                ++tk;
             } else {
-                unsigned mask;
-                if constexpr (NW > 0) {
-                    if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
-                    mask = cur & 15u;   // zero codes were turned into 15 when the word was packed
-                    cur >>= 4;
-                    ++tk;
-                } else {
-                    mask = st & 15u;
-                    mask = mask ? mask : 15u;
-                }
-                const double* w = wtab + mask * 4;
+                mask = st & 15u;
+                mask = mask ? mask : 15u;
+            }
+            const double* w = wtab + mask * 4;
+            if (op.code == OP_TIP_SET) {
+                // A subtree starts here (program start, or right after a PUSH: tree_program.hpp emits no other
+                // TIP_SET): the tip's message IS the new accumulator -- no product with an identity, no rescaling.
+                const double wv[4] = {w[0], w[1], w[2], w[3]};
+                tip_message_over(R, etab, wv, op.t * s, acc);
+            } else {
+                Partial m;
                 const double f = rescale_factor(acc, scale);
                 const double wv[4] = {w[0] * f, w[1] * f, w[2] * f, w[3] * f};
                 tip_message(R, etab, wv, op.t * s, m);
+                partial_mul(acc, m);
+            }
+        } else if (op.code == OP_POP_MUL) {
+            Partial m;
+            --sp;
+            const double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                m.v[i] = slot[(i)*kSiteBlock];
+                m.d1[i] = slot[(4 + i) * kSiteBlock];
+                m.d2[i] = slot[(8 + i) * kSiteBlock];
             }
             partial_mul(acc, m);
         } else if (op.code == OP_BRANCH) {
             const double f = rescale_factor(acc, scale);
             branch_apply(R, etab, op.t * s, f, acc);
-        } else {  // OP_PUSH: park the finished sibling, start the next subtree from the identity
+        } else {  // OP_PUSH: park the finished sibling; the TIP_SET that always follows overwrites the accumulator
             double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 slot[(i)*kSiteBlock] = acc.v[i];
                 slot[(4 + i) * kSiteBlock] = acc.d1[i];
                 slot[(8 + i) * kSiteBlock] = acc.d2[i];
-                acc.v[i] = 1.0; acc.d1[i] = 0.0; acc.d2[i] = 0.0;
             }
             ++sp;
         }
