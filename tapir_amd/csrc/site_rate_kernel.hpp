@@ -161,8 +161,25 @@ __device__ __forceinline__ void tip_message(const ModelRegs& R, const double* __
     }
 }
 
-// the same message written over `acc` (TIP_SET: the accumulator's previous content is dead), results pinned to the
-// registers the loop carries
+// U * (a, b, c) written over `acc` (whose previous content is dead), results pinned to the registers the loop carries
+__device__ __forceinline__ void message_over(const ModelRegs& R, const double (&a)[3], const double (&b)[3], const double (&c)[3],
+                                             double w0, Partial& acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double* Ur = R.U + i * 3;
+        fma_over(acc.v[i], Ur[0], a[0], w0);
+        fma_into(acc.v[i], Ur[1], a[1]);
+        fma_into(acc.v[i], Ur[2], a[2]);
+        mul_over(acc.d1[i], Ur[0], b[0]);
+        fma_into(acc.d1[i], Ur[1], b[1]);
+        fma_into(acc.d1[i], Ur[2], b[2]);
+        mul_over(acc.d2[i], Ur[0], c[0]);
+        fma_into(acc.d2[i], Ur[1], c[1]);
+        fma_into(acc.d2[i], Ur[2], c[2]);
+    }
+}
+
+// TIP_SET: the tip's message becomes the accumulator
 __device__ __forceinline__ void tip_message_over(const ModelRegs& R, const double* __restrict__ etab, const double* w, double ts, Partial& acc) {
     double a[3], b[3], c[3];
 #pragma unroll
@@ -173,19 +190,38 @@ __device__ __forceinline__ void tip_message_over(const ModelRegs& R, const doubl
         b[k] = x * a[k];
         c[k] = fma(x, b[k], b[k]);
     }
+    message_over(R, a, b, c, w[0], acc);
+}
+
+// CHERRY: two tips on equally long branches start a subtree; exp(lambda_k t s) is computed once for both messages
+// (w1 -> accumulator, w2 -> multiplied in).
+__device__ __forceinline__ void cherry_over(const ModelRegs& R, const double* __restrict__ etab, const double* w1, const double* w2,
+                                            double ts, Partial& acc) {
+    double x[3], e[3], a[3], b[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        x[k] = R.lam[k] * ts;
+        e[k] = kUseExpTable ? exp_nonpos_tab(x[k], etab) : exp_nonpos(x[k]);
+        a[k] = e[k] * w1[k + 1];
+        b[k] = x[k] * a[k];
+        c[k] = fma(x[k], b[k], b[k]);
+    }
+    message_over(R, a, b, c, w1[0], acc);
+    Partial m;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a[k] = e[k] * w2[k + 1];
+        b[k] = x[k] * a[k];
+        c[k] = fma(x[k], b[k], b[k]);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double* Ur = R.U + i * 3;
-        fma_over(acc.v[i], Ur[0], a[0], w[0]);
-        fma_into(acc.v[i], Ur[1], a[1]);
-        fma_into(acc.v[i], Ur[2], a[2]);
-        mul_over(acc.d1[i], Ur[0], b[0]);
-        fma_into(acc.d1[i], Ur[1], b[1]);
-        fma_into(acc.d1[i], Ur[2], b[2]);
-        mul_over(acc.d2[i], Ur[0], c[0]);
-        fma_into(acc.d2[i], Ur[1], c[1]);
-        fma_into(acc.d2[i], Ur[2], c[2]);
+        m.v[i] = fma(Ur[2], a[2], fma(Ur[1], a[1], fma(Ur[0], a[0], w2[0])));
+        m.d1[i] = fma(Ur[2], b[2], fma(Ur[1], b[1], Ur[0] * b[0]));
+        m.d2[i] = fma(Ur[2], c[2], fma(Ur[1], c[1], Ur[0] * c[0]));
     }
+    partial_mul(acc, m);
 }
 
 // acc <- P(t s) * acc with derivatives (internal branch)
@@ -370,6 +406,21 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
                 tip_message(R, etab, wv, op.t * s, m);
                 partial_mul(acc, m);
             }
+        } else if (NW > 0 && op.code == OP_CHERRY) {   // fused stream (packed path only)
+            unsigned mask1, mask2;
+            if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
+            mask1 = cur & 15u;
+            cur >>= 4;
+            ++tk;
+            if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
+            mask2 = cur & 15u;
+            cur >>= 4;
+            ++tk;
+            const double* w1 = wtab + mask1 * 4;
+            const double* w2 = wtab + mask2 * 4;
+            const double wa[4] = {w1[0], w1[1], w1[2], w1[3]};
+            const double wb[4] = {w2[0], w2[1], w2[2], w2[3]};
+            cherry_over(R, etab, wa, wb, op.t * s, acc);
         } else if (op.code == OP_POP_MUL) {
             Partial m;
             --sp;

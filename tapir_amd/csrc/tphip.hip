@@ -84,7 +84,7 @@ struct tphip_plan {
     std::vector<int64_t> h_offsets;
     int64_t n_site_chunks = 0, n_pi_chunks = 0;
     int32_t site_chunk_cols = kSiteBlock;  // columns per site_rate_kernel work slice (multiple of 64)
-    DevBuf<TreeOp> d_ops;
+    DevBuf<TreeOp> d_ops, d_fused_ops;
     DevBuf<LocusModel> d_models;
     DevBuf<int64_t> d_offsets, d_locus_pichunk_offsets;
     DevBuf<int32_t> d_tip_taxon, d_op_node;
@@ -141,7 +141,7 @@ int tphip_device_count(void) {
 int tphip_plan_destroy(tphip_plan* plan) {
     if (!plan) return TPHIP_OK;
     (void)hipSetDevice(plan->device);
-    plan->d_ops.release(); plan->d_models.release(); plan->d_offsets.release();
+    plan->d_ops.release(); plan->d_fused_ops.release(); plan->d_models.release(); plan->d_offsets.release();
     plan->d_locus_pichunk_offsets.release(); plan->d_site_chunk_locus.release(); plan->d_site_chunk_index.release();
     plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
     plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
@@ -264,6 +264,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     }
     p->nnodes = d->nnodes;
     if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
+    if (e == hipSuccess) e = p->d_fused_ops.upload(p->prog.fused_ops);
     if (e == hipSuccess) e = p->d_offsets.upload(p->h_offsets);
     if (e == hipSuccess) e = p->d_locus_pichunk_offsets.upload(lpo);
     if (e == hipSuccess) e = p->d_site_chunk_locus.upload(scl);
@@ -465,12 +466,16 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
         const dim3 grid((unsigned)(p->site_persistent ? p->site_waves : p->n_site_chunks)), block(kSiteBlock);
         // register-resident tip states for up to 256 tips; beyond that the byte path (NW = 0)
         const char* fb = getenv("TPHIP_FORCE_BYTE_PATH");  // test/tuning knob: exercise the NW = 0 kernel on any tree
-        if (fb && fb[0] == '1') site_rate_kernel<0><<<grid, block, lds, st>>>(S);
+        const bool byte_path = (fb && fb[0] == '1') || p->nwords > 32;
+        if (!byte_path) {  // the packed path reads the stream with fused cherries (tree_program.hpp)
+            S.ops = p->d_fused_ops.p;
+            S.nops = (int32_t)p->prog.fused_ops.size();
+        }
+        if (byte_path) site_rate_kernel<0><<<grid, block, lds, st>>>(S);
         else if (p->nwords <= 2) site_rate_kernel<2><<<grid, block, lds, st>>>(S);
         else if (p->nwords <= 8) site_rate_kernel<8><<<grid, block, lds, st>>>(S);
         else if (p->nwords <= 16) site_rate_kernel<16><<<grid, block, lds, st>>>(S);
-        else if (p->nwords <= 32) site_rate_kernel<32><<<grid, block, lds, st>>>(S);
-        else site_rate_kernel<0><<<grid, block, lds, st>>>(S);
+        else site_rate_kernel<32><<<grid, block, lds, st>>>(S);
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));
     HIP_TRY(hipGetLastError());

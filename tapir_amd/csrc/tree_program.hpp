@@ -23,7 +23,8 @@
 
 namespace tphip {
 
-enum : int32_t { OP_TIP_SET = 0, OP_TIP_MUL = 1, OP_BRANCH = 2, OP_PUSH = 3, OP_POP_MUL = 4 };
+enum : int32_t { OP_TIP_SET = 0, OP_TIP_MUL = 1, OP_BRANCH = 2, OP_PUSH = 3, OP_POP_MUL = 4,
+                 OP_CHERRY = 5 };  // fused stream only: TIP_SET + TIP_MUL on equally long branches
 
 struct TreeOp {
     int32_t code;
@@ -34,6 +35,10 @@ static_assert(sizeof(TreeOp) == 16, "TreeOp is read with one s_load_dwordx4");
 
 struct TreeProgram {
     std::vector<TreeOp> ops;
+    // The same program with every TIP_SET + TIP_MUL pair on equally long branches (the two tips of a cherry in a
+    // chronogram) folded into one CHERRY op: both messages share exp(lambda_k t s).  Tip order is unchanged, so the
+    // packed tip words of classify_kernel serve both streams.  Only site_rate_kernel's packed path reads it.
+    std::vector<TreeOp> fused_ops;
     std::vector<int32_t> op_node;  // tree node whose branch a TIP_* / BRANCH op climbs (-1 for PUSH / POP_MUL)
     std::vector<int32_t> op_tape;     // reverse-mode tape slot written by a BRANCH / PUSH op (-1 otherwise)
     std::vector<int32_t> op_partner;  // POP_MUL: tape slot of the PUSH it pops (-1 otherwise)
@@ -144,6 +149,17 @@ inline std::string build_tree_program(int32_t ntaxa, int32_t nnodes, const int32
         }
     }
     if (!pushed.empty()) return "internal error: unbalanced PUSH";
+    out->fused_ops.clear();
+    for (size_t i = 0; i < out->ops.size(); ++i) {
+        const TreeOp& a = out->ops[i];
+        if (a.code == OP_TIP_SET && i + 1 < out->ops.size() && out->ops[i + 1].code == OP_TIP_MUL &&
+            out->ops[i + 1].t == a.t) {
+            out->fused_ops.push_back({OP_CHERRY, a.taxon, a.t});
+            ++i;
+        } else {
+            out->fused_ops.push_back(a);
+        }
+    }
     return "";
 }
 
