@@ -35,9 +35,11 @@ def flops_per_eval(oc):
       exp_nonpos_tab                  19  (max, fma, add, 2 fma, 4 fma + mul, fma)
       tip message                    137  (3 exp + 15 + 64 + 1)
       internal branch                244  (84 for U^-1 v/v'/v'', 3 exp + 30, 72 for U, 1)
-      product rule (TIP_*/POP_MUL)    40
+      product rule (TIP_MUL/POP_MUL)  40  (TIP_SET writes its message into the accumulator: no product)
+      fused cherry                   -57  (the second tip reuses the first one's 3 exponentials)
       root: L, L', L'' + log, div   ~ 50"""
-    return ((oc["tip_set"] + oc["tip_mul"]) * (137 + 40) + oc["pop_mul"] * 40 + oc["branch"] * 244 + 50)
+    return (oc["tip_set"] * 137 + oc["tip_mul"] * (137 + 40) + oc["pop_mul"] * 40 + oc["branch"] * 244 + 50
+            - oc.get("cherry", 0) * 57)
 
 
 def main():

@@ -367,6 +367,13 @@ int tphip_plan_op_counts(const tphip_plan* p, int32_t* counts) {
     return TPHIP_OK;
 }
 
+int32_t tphip_plan_cherry_count(const tphip_plan* p) {
+    if (!p || p->nwords > 32) return 0;
+    int32_t n = 0;
+    for (const TreeOp& op : p->prog.fused_ops) n += (op.code == OP_CHERRY);
+    return n;
+}
+
 int tphip_plan_get_models(const tphip_plan* p, double* lam, double* U, double* Uinv, double* kappa) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
     HIP_TRY(hipSetDevice(p->device));

@@ -45,6 +45,7 @@ SYMBOLS = [
     ("tphip_plan_chrono_length", _f64, [_vp]),
     ("tphip_plan_stack_depth", _i32, [_vp]),
     ("tphip_plan_op_counts", ctypes.c_int, [_vp, _vp]),
+    ("tphip_plan_cherry_count", _i32, [_vp]),
     ("tphip_plan_get_models", ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("tphip_site_rates_dev", ctypes.c_int, [_vp] * 8 + [ctypes.c_size_t, _vp]),
     ("tphip_pi_tables_dev", ctypes.c_int, [_vp] * 5 + [ctypes.c_size_t, _vp]),
@@ -162,6 +163,7 @@ class Plan:
         oc = np.zeros(5, np.int32)
         _check(lib.tphip_plan_op_counts(self._h, oc.ctypes.data))
         self.op_counts = dict(zip(("tip_set", "tip_mul", "branch", "push", "pop_mul"), oc.tolist()))
+        self.op_counts["cherry"] = int(lib.tphip_plan_cherry_count(self._h))
 
     def close(self):
         if self._h:
