@@ -1,6 +1,9 @@
 """Randomised GPU-vs-oracle parity sweep (not part of the test suite: minutes of CPU oracle time).
 Random trees (binary and with polytomies), taxa 2..90, ragged loci, gaps / IUPAC codes, extreme rates and frequencies.
-usage: python tools/fuzz_parity.py [NCASES] [SEED] [MAX_TAXA] [ZERO_FRACTION]
+usage: python tools/fuzz_parity.py [NCASES] [SEED] [MAX_TAXA] [ZERO_FRACTION] [EQUAL_CHERRY_FRACTION]
+
+EQUAL_CHERRY_FRACTION (default 0.5): share of the two-tip joins whose tips get the SAME branch length, as in a
+chronogram -- those are the pairs site_rate_kernel executes as one fused CHERRY op.
 
 ZERO_FRACTION > 0 sets that share of the internal branches to length 0 (exploratory): together with very short tips and
 noisy data it produces columns whose likelihood is at the rounding level of its own terms (a change would have to
@@ -16,6 +19,7 @@ ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 MAX_TAXA = int(sys.argv[3]) if len(sys.argv) > 3 else 90          # optional third argument: largest tree
 ZERO_BRANCHES = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0   # optional fourth: fraction of zero-length INTERNAL branches
+EQUAL_CHERRIES = float(sys.argv[5]) if len(sys.argv) > 5 else 0.5  # optional fifth: fraction of cherries with equal tip lengths
 CODES = np.array([1, 2, 4, 8, 15, 15, 5, 10, 3, 12, 7, 0], dtype=np.uint8)
 
 
@@ -30,6 +34,8 @@ def random_tree(n):
         k = 2 if (len(nodes) < 3 or rng.random() < 0.85) else min(len(nodes), int(rng.integers(3, 5)))
         idx = rng.choice(len(nodes), size=k, replace=False)
         kids = [nodes[i] for i in idx]
+        if k == 2 and all("(" not in x for x in kids) and rng.random() < EQUAL_CHERRIES:
+            kids[1] = kids[1].rsplit(":", 1)[0] + ":" + kids[0].rsplit(":", 1)[1]   # a cherry of a chronogram
         nodes = [x for j, x in enumerate(nodes) if j not in set(idx.tolist())]
         nodes.append("(%s):%g" % (",".join(kids), length()))
     return nodes[0].rsplit(":", 1)[0] + ";"
