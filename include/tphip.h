@@ -122,7 +122,7 @@ int32_t tphip_plan_stack_depth(const tphip_plan *plan);
 /* op mix of the compiled tree program: counts[5] = TIP_SET, TIP_MUL, BRANCH, PUSH, POP_MUL (for FLOP models) */
 int tphip_plan_op_counts(const tphip_plan *plan, int32_t *counts);
 /* number of TIP_SET + TIP_MUL pairs the site-rate kernel executes as one fused CHERRY op (equal branch lengths:
- * one set of exponentials for both tips); 0 when the tree has more than 256 tips (byte path, plain stream) */
+ * one set of exponentials for both tips) */
 int32_t tphip_plan_cherry_count(const tphip_plan *plan);
 /* copy the per-locus eigen-systems back (tests): lam[L*4], U[L*16], Uinv[L*16], kappa[L] */
 int tphip_plan_get_models(const tphip_plan *plan, double *lam, double *U, double *Uinv, double *kappa);

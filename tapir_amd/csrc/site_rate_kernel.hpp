@@ -338,11 +338,16 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&pk)[NW > 0 ? NW :
     }
 }
 
+constexpr int kStreamWords = -1;   // NW value of the streamed-words path
+
 // One likelihood evaluation for this lane's column: f = log L, g = df/du, h = d2f/du2 at s = exp(u).
 // NW > 0: the column's tip states live in registers (pk: 8 four-bit masks per word, in program tip order), so
 //         the Newton iterations never touch the alignment again;
-// NW = 0: states are fetched from the byte array one op ahead (trees with more than 256 tips, and the
-//         eval_columns diagnostic, which thereby cross-checks the packed path).
+// NW = kStreamWords: more than 64 tips -- the packed words would take 16+ registers and push the kernel past 256
+//         VGPRs (one wave per SIMD).  Only word 0 stays in a register; word w + 1 is requested from the packed array
+//         (L2-resident: 4 bytes per 8 tips per evaluation) when word w is started, i.e. eight ops before it is needed;
+// NW = 0: states are fetched from the byte array one op ahead (the eval_columns diagnostic, which thereby
+//         cross-checks the packed paths, and TPHIP_FORCE_BYTE_PATH).
 template <int NW>
 __device__ __forceinline__ void evaluate_column(const SiteParams& P, const ModelRegs& R, const double* __restrict__ wtab,
                                                 const double* __restrict__ etab, double* __restrict__ stack, int64_t col,
@@ -372,6 +377,30 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
         op = sop_decode(r0);
         nxt = sop_decode(r1);
     }
+    uint32_t nxtw = 0;   // streamed path: the word after the current one, in flight
+    if constexpr (NW == kStreamWords) nxtw = pk[0];
+    auto next_mask = [&]() -> unsigned {   // the next tip's 4-bit mask, in program order (tk is wave-uniform)
+        if constexpr (NW > 0) {
+            if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
+        } else if constexpr (NW == kStreamWords) {
+            if ((tk & 7) == 0) {
+                // The request for word w + 1 must stay in flight for the next eight ops: as a plain load the compiler
+                // waits for it at the end of this block (the value has to reach the register the loop carries).  Issued
+                // and awaited by hand, both statements tied ("+v") to that one register (section 5.7, form ii); word 0
+                // never passes through here in flight: pk[0] is an ordinary load.
+                if (tk > 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxtw));
+                cur = nxtw;
+                int w = (tk >> 3) + 1;
+                w = w < P.nwords ? w : P.nwords - 1;
+                const uint32_t* src = P.packed + ((int64_t)w * P.ncols_total + col);
+                asm volatile("global_load_dword %0, %1, off" : "+v"(nxtw) : "v"(src));
+            }
+        }
+        const unsigned m = cur & 15u;
+        cur >>= 4;
+        ++tk;
+        return m;
+    };
     unsigned st = 15u;
     if constexpr (NW == 0) st = load_state(P, op.taxon, col);  // the program always starts at a tip
     for (int ip = 0; ip < P.nops; ++ip) {
@@ -384,11 +413,8 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
         }
         if (op.code <= OP_TIP_MUL) {
             unsigned mask;
-            if constexpr (NW > 0) {
-                if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
-                mask = cur & 15u;   // zero codes were turned into 15 when the word was packed
-                cur >>= 4;
-                ++tk;
+            if constexpr (NW != 0) {
+                mask = next_mask();   // zero codes were turned into 15 when the word was packed
             } else {
                 mask = st & 15u;
                 mask = mask ? mask : 15u;
@@ -406,16 +432,9 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
                 tip_message(R, etab, wv, op.t * s, m);
                 partial_mul(acc, m);
             }
-        } else if (NW > 0 && op.code == OP_CHERRY) {   // fused stream (packed path only)
-            unsigned mask1, mask2;
-            if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
-            mask1 = cur & 15u;
-            cur >>= 4;
-            ++tk;
-            if ((tk & 7) == 0) cur = pick_word<NW>(pk, tk >> 3);
-            mask2 = cur & 15u;
-            cur >>= 4;
-            ++tk;
+        } else if (NW != 0 && op.code == OP_CHERRY) {   // fused stream (packed paths only)
+            const unsigned mask1 = next_mask();
+            const unsigned mask2 = next_mask();
             const double* w1 = wtab + mask1 * 4;
             const double* w2 = wtab + mask2 * 4;
             const double wa[4] = {w1[0], w1[1], w1[2], w1[3]};
@@ -450,6 +469,8 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
         nxt = sop_decode(raw);
         st = st_nxt;
     }
+    // the last word's (clamped, unused) request must have landed before its register is reused
+    if constexpr (NW == kStreamWords) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxtw));
     double L = 0, L1 = 0, L2 = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -596,6 +617,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         uint32_t pk[NW > 0 ? NW : 1] = {0};
 #pragma unroll
         for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
+        if constexpr (NW == kStreamWords) pk[0] = P.packed[col];
         // start: classify_kernel left the column's parsimony-based log rate in its `rate` slot (pi_kernels.hpp)
         double u = done ? 0.0 : P.rate[col], lo = kUMin, hi = kUMax, u_prev = 0.0, h_prev = 0.0, g_prev = 0.0;
         bool lo_open = true, hi_open = true, have_prev = false;
@@ -713,6 +735,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     col = work[idx];
 #pragma unroll
                     for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
+                    if constexpr (NW == kStreamWords) pk[0] = P.packed[col];
                     u = P.rate[col]; lo = kUMin; hi = kUMax; lo_open = true; hi_open = true; have_prev = false; it = 0;
                     checking = false;
                     done = false;

@@ -299,9 +299,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         hipError_t oe;
         if (p->nwords <= 2) oe = occ(site_rate_kernel<2>);
         else if (p->nwords <= 8) oe = occ(site_rate_kernel<8>);
-        else if (p->nwords <= 16) oe = occ(site_rate_kernel<16>);
-        else if (p->nwords <= 32) oe = occ(site_rate_kernel<32>);
-        else oe = occ(site_rate_kernel<0>);
+        else oe = occ(site_rate_kernel<kStreamWords>);
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         p->site_waves = per_cu * prop.multiProcessorCount;
         p->num_cus = prop.multiProcessorCount;
@@ -368,7 +366,7 @@ int tphip_plan_op_counts(const tphip_plan* p, int32_t* counts) {
 }
 
 int32_t tphip_plan_cherry_count(const tphip_plan* p) {
-    if (!p || p->nwords > 32) return 0;
+    if (!p) return 0;
     int32_t n = 0;
     for (const TreeOp& op : p->prog.fused_ops) n += (op.code == OP_CHERRY);
     return n;
@@ -471,9 +469,9 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_site_chunks > 0) {
         const dim3 grid((unsigned)(p->site_persistent ? p->site_waves : p->n_site_chunks)), block(kSiteBlock);
-        // register-resident tip states for up to 256 tips; beyond that the byte path (NW = 0)
+        // packed tip states: in registers up to 64 tips, streamed one word ahead beyond (site_rate_kernel.hpp)
         const char* fb = getenv("TPHIP_FORCE_BYTE_PATH");  // test/tuning knob: exercise the NW = 0 kernel on any tree
-        const bool byte_path = (fb && fb[0] == '1') || p->nwords > 32;
+        const bool byte_path = (fb && fb[0] == '1');
         if (!byte_path) {  // the packed path reads the stream with fused cherries (tree_program.hpp)
             S.ops = p->d_fused_ops.p;
             S.nops = (int32_t)p->prog.fused_ops.size();
@@ -481,8 +479,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
         if (byte_path) site_rate_kernel<0><<<grid, block, lds, st>>>(S);
         else if (p->nwords <= 2) site_rate_kernel<2><<<grid, block, lds, st>>>(S);
         else if (p->nwords <= 8) site_rate_kernel<8><<<grid, block, lds, st>>>(S);
-        else if (p->nwords <= 16) site_rate_kernel<16><<<grid, block, lds, st>>>(S);
-        else site_rate_kernel<32><<<grid, block, lds, st>>>(S);
+        else site_rate_kernel<kStreamWords><<<grid, block, lds, st>>>(S);   // more than 64 tips
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));
     HIP_TRY(hipGetLastError());
