@@ -52,6 +52,9 @@
 #endif
 #define ORC_STEP_TOL_FIRST 1e-6 /* ... except at the first evaluation, where no second point exists yet */
 #define ORC_MAXIT 100
+#ifndef ORC_PLATEAU_STRIDE
+#define ORC_PLATEAU_STRIDE 0.5
+#endif
 #define ORC_U_CHECK 2.995732273553991 /* log(20): optima beyond this rate are confirmed by value, see maximise_column */
 #define ORC_SAT_TOL 1e-10
 #ifndef ORC_HERMITE_TOL /* 0 switches the rule off (accuracy experiments against a tight reference) */
@@ -734,6 +737,12 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
         }
         if (!(step <= ORC_STEP_MAX)) step = ORC_STEP_MAX;
         if (step < -ORC_STEP_MAX) step = -ORC_STEP_MAX;
+        /* Plateau stride: still uphill at a rate of 20 or more with nothing known above is almost always a column whose
+         * log L creeps up to its s -> infinity asymptote; g and h shrink together there, the model behind the step sees a
+         * maximum just ahead and the steps stay at ~0.1 for 20-30 evaluations until the flatness rule fires.  A stride
+         * of at least ORC_PLATEAU_STRIDE covers the two log-units to flatness in a few evaluations; a maximum that does
+         * lie ahead is overshot by at most that much and then bracketed from both sides. */
+        if (uphill && hi_open && u >= ORC_U_CHECK && step < ORC_PLATEAU_STRIDE) step = ORC_PLATEAU_STRIDE;
         /* With two evaluations in hand, f' is known with its slope at both points: the cubic Hermite interpolant of f'
          * through (u_prev, g_prev, h_prev) and (u, g, h) locates the zero to fourth order, so a remaining step of up to
          * 1e-3 can be taken WITHOUT evaluating again (at 2e-3 the worst residual over 8e5 columns reached 1.2e-6; the

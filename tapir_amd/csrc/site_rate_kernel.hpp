@@ -47,6 +47,7 @@ constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp6
 // by value: if log L at the largest rate is not lower by more than kSatTol (relative), the column is saturated.
 constexpr double kUCheck = 2.995732273553991;   // log(20)
 constexpr double kSatTol = 1e-10;
+constexpr double kPlateauStride = 0.5;
 constexpr int kSiteBlock = 64;      // one wavefront per workgroup
 constexpr int kSiteLdsHeader = 160;  // doubles of LDS before the stack: tip table [16][4] + model [32] + 2^(j/64) [64]
 #ifndef TPHIP_EXP_TABLE
@@ -71,6 +72,7 @@ struct SiteParams {
     const int32_t* work_cols;      // [ncols_total] compacted column ids, per locus at locus_offsets[l]
     const int32_t* work_count;     // [nloci]
     const int64_t* work_prefix;    // [nloci+1] exclusive scan of work_count (scan_counts_kernel)
+    const int64_t* slice_prefix;   // [nloci+1] exclusive scan of the per-locus slice counts (non-persistent mode)
     int64_t nloci;
     int32_t persistent;            // 1: grid = resident waves, equal shares of the global work list; 0: grid = slices
     int32_t ncat;                  // > 1: discrete rate mixture on top of the site rate (tphip_plan_desc.ncat)
@@ -527,25 +529,42 @@ __device__ __forceinline__ void build_tip_table(const LocusModel* __restrict__ M
     wtab[lane] = w;
 }
 
-// Exclusive scan of the per-locus work counts (one workgroup; L is at most a few 10^4).
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* __restrict__ count, int64_t nloci,
-                                                           int64_t* __restrict__ prefix) {
+// Slices a locus with `count` optimiser columns is cut into in the non-persistent mode: about chunk_cols each.
+__host__ __device__ __forceinline__ int site_slices(int count, int chunk_cols) {
+    if (count <= 0) return 0;
+    const int ns = (count + chunk_cols / 2) / chunk_cols;
+    return ns < 1 ? 1 : ns;
+}
+
+// Exclusive scans of the per-locus work counts and of the per-locus slice counts (one workgroup; L is at most a
+// few 10^4).
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* __restrict__ count, int64_t nloci, int32_t chunk_cols,
+                                                           int64_t* __restrict__ prefix, int64_t* __restrict__ slice_prefix) {
     __shared__ long long part[1024];
+    __shared__ long long spart[1024];
     const int t = threadIdx.x;
     const int64_t per = (nloci + 1023) / 1024;
     const int64_t lo = t * per, hi = (lo + per < nloci) ? lo + per : nloci;
-    long long s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += count[i];
+    long long s = 0, q = 0;
+    for (int64_t i = lo; i < hi; ++i) { s += count[i]; q += site_slices(count[i], chunk_cols); }
     part[t] = s;
+    spart[t] = q;
     __syncthreads();
     if (t == 0) {
-        long long run = 0;
-        for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+        long long run = 0, srun = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const long long v = part[i]; part[i] = run; run += v;
+            const long long w = spart[i]; spart[i] = srun; srun += w;
+        }
         prefix[nloci] = run;
+        slice_prefix[nloci] = srun;
     }
     __syncthreads();
-    long long run = part[t];
-    for (int64_t i = lo; i < hi; ++i) { prefix[i] = run; run += count[i]; }
+    long long run = part[t], srun = spart[t];
+    for (int64_t i = lo; i < hi; ++i) {
+        prefix[i] = run; run += count[i];
+        slice_prefix[i] = srun; srun += site_slices(count[i], chunk_cols);
+    }
 }
 
 // Persistent, statically balanced launch: the grid is exactly the number of waves the chip keeps resident;
@@ -582,16 +601,23 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         }
     } else {
         // Small batches (a share would be a few hundred columns): one workgroup per locus-aligned slice instead,
-        // because cutting a small locus in two doubles its prologue and drain.  The locus' `count` columns are
-        // split into `ns` EQUAL slices of about chunk_cols; the grid was sized for the worst case (every column
-        // needs the optimiser) and surplus workgroups leave at once.
-        lo_l = P.chunk_locus[blockIdx.x];
+        // because cutting a small locus in two doubles its prologue and drain.  A locus' `count` columns are split
+        // into site_slices(count) EQUAL slices; workgroup b takes the b-th slice of the batch, located through the
+        // prefix sums of the per-locus slice counts.  The grid was sized for the worst case (every column needs the
+        // optimiser); the surplus workgroups are the LAST ones of the grid and leave at once -- interleaved with the
+        // working ones (one fixed slot per possible slice) they alias with the round-robin of workgroups over the 8
+        // XCDs: with two slots per locus and one in use, four XCDs did all the work.
+        const int64_t nslices = P.slice_prefix[P.nloci];
+        if ((int64_t)blockIdx.x >= nslices) return;
+        int64_t hi_l = P.nloci;
+        lo_l = 0;
+        while (hi_l - lo_l > 1) {
+            const int64_t mid = (lo_l + hi_l) >> 1;
+            if (P.slice_prefix[mid] <= (int64_t)blockIdx.x) lo_l = mid; else hi_l = mid;
+        }
         const int count = P.work_count[lo_l];
-        if (count == 0) return;
-        int ns = (count + P.chunk_cols / 2) / P.chunk_cols;
-        ns = ns < 1 ? 1 : ns;
-        const int j = P.chunk_index[blockIdx.x];
-        if (j >= ns) return;
+        const int ns = site_slices(count, P.chunk_cols);
+        const int j = (int)((int64_t)blockIdx.x - P.slice_prefix[lo_l]);
         const int64_t pbeg = P.work_prefix[lo_l];
         g0 = pbeg + (int64_t)j * count / ns;
         g1 = pbeg + (int64_t)(j + 1) * count / ns;
@@ -685,6 +711,13 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     }
                     if (!(step <= kStepMax)) step = kStepMax;
                     if (step < -kStepMax) step = -kStepMax;
+                    // Plateau stride (same rule as the oracle): still uphill at a rate of 20 or more with nothing known
+                    // above is almost always a column whose log L creeps up to its s -> infinity asymptote; g and h shrink
+                    // together there and the steps stay at ~0.1 for 20-30 evaluations until the flatness rule fires --
+                    // and in a small batch one such lane keeps its whole wave alive.  A stride of at least
+                    // kPlateauStride covers the two log-units to flatness in a few evaluations; a maximum that does lie
+                    // ahead is overshot by at most that much and then bracketed from both sides.
+                    if (uphill && hi_open && u >= kUCheck && step < kPlateauStride) step = kPlateauStride;
                     const double tol = have_prev ? kStepTol : kStepTolFirst;
                     un = u + step;
                     // the bracket safeguard must not see a converged (possibly underflowing) step

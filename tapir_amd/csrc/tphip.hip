@@ -114,7 +114,7 @@ struct tphip_plan {
     DevBuf<int32_t> d_site_chunk_locus, d_site_chunk_index, d_pi_chunk_locus, d_pi_chunk_index, d_times, d_intervals;
     DevBuf<unsigned long long> d_evals;
     // workspace layout (bytes)
-    size_t ws_work_cols = 0, ws_work_count = 0, ws_work_prefix = 0, ws_partial = 0, ws_packed = 0, ws_total = 0;
+    size_t ws_work_cols = 0, ws_work_count = 0, ws_work_prefix = 0, ws_slice_prefix = 0, ws_partial = 0, ws_packed = 0, ws_total = 0;
     int32_t num_cus = 256;
     int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
     int32_t site_persistent = 1;
@@ -345,6 +345,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->ws_work_cols = off; off = align_up(off + sizeof(int32_t) * (size_t)ncols, 256);
     p->ws_work_count = off; off = align_up(off + sizeof(int32_t) * (size_t)d->nloci, 256);
     p->ws_work_prefix = off; off = align_up(off + sizeof(int64_t) * ((size_t)d->nloci + 1), 256);
+    p->ws_slice_prefix = off; off = align_up(off + sizeof(int64_t) * ((size_t)d->nloci + 1), 256);
     p->ws_partial = off; off = align_up(off + sizeof(double) * (size_t)p->n_pi_chunks * (size_t)(d->T + 2 * d->n_i), 256);
     p->ws_packed = off; off = align_up(off + sizeof(uint32_t) * (size_t)p->nwords * (size_t)ncols, 256);
     p->ws_total = off + 256;
@@ -450,7 +451,8 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
         compact_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
-        scan_counts_kernel<<<dim3(1), dim3(1024), 0, st>>>(work_count, p->nloci, (int64_t*)((char*)ws + p->ws_work_prefix));
+        scan_counts_kernel<<<dim3(1), dim3(1024), 0, st>>>(work_count, p->nloci, p->site_chunk_cols, (int64_t*)((char*)ws + p->ws_work_prefix),
+                                                           (int64_t*)((char*)ws + p->ws_slice_prefix));
     }
     HIP_TRY(hipMemsetAsync(p->d_evals.p, 0, sizeof(unsigned long long), st));
     SiteParams S;
@@ -461,6 +463,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.packed = (const uint32_t*)((char*)ws + p->ws_packed); S.nwords = p->nwords;
     S.work_cols = work_cols; S.work_count = work_count;
     S.work_prefix = (const int64_t*)((char*)ws + p->ws_work_prefix); S.nloci = p->nloci;
+    S.slice_prefix = (const int64_t*)((char*)ws + p->ws_slice_prefix);
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     S.persistent = p->site_persistent;
