@@ -302,6 +302,42 @@ def test_site_rate_kernel_variants(oracle, monkeypatch, persistent, byte_path):
         plan.close()
 
 
+def test_fused_cherries_follow_the_branch_lengths(oracle):
+    """The packed path folds TIP_SET + TIP_MUL on EQUALLY long branches into one CHERRY op (shared exponentials).
+    A chronogram's cherries all qualify; lengthening one tip of a cherry must take exactly that pair out of the
+    fused stream and leave the results equal to the oracle's either way."""
+    engine = _engine()
+    from tapir_amd import synth
+    d = synth.simulate(2, 600, 64, synth.WORKLOAD_SEED["C3"], tree=synth.yule_tree(64, synth.WORKLOAD_SEED["C3"]))
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    parent, blen, leaf = np.asarray(pin["parent"]), np.asarray(pin["blen"], dtype=np.float64).copy(), np.asarray(pin["leaf"])
+    # cherries of the tree: internal nodes whose children are two leaves
+    kids = {}
+    for n, p in enumerate(parent):
+        if p >= 0:
+            kids.setdefault(int(p), []).append(n)
+    cherries = [k for k in kids.values() if len(k) == 2 and all(leaf[c] >= 0 for c in k)]
+    assert len(cherries) == 21
+    counts = []
+    for variant in range(2):
+        if variant == 1:
+            blen[cherries[0][0]] *= 1.25   # no longer equal to its sibling
+        plan = engine.Plan(64, parent, blen, leaf, d["locus_offsets"], d["pi"], d["exch"], pin["T"], [10], [[5, 15]],
+                           correction=pin["correction"])
+        counts.append(plan.op_counts["cherry"])
+        got = plan.site_rates(st)
+        kappa = plan.models()[3]
+        off = d["locus_offsets"]
+        for l in range(2):
+            sl = slice(int(off[l]), int(off[l + 1]))
+            ref = oracle.site_rates(st[:, sl], parent, blen, leaf, d["pi"][l], d["exch"][l])
+            assert np.array_equal(got["flag"][sl], ref["flag"])
+            _assert_rates_match(oracle, got, ref, sl, st[:, sl], dict(pin, blen=blen), d["pi"][l], d["exch"][l], kappa[l])
+        plan.close()
+    assert counts == [21, 20]
+
+
 def test_hyphy_protocol_shim(golden_dir, tmp_path, oracle):
     """Boundary #1: `--hyphy /path/to/tphip_hyphy` -- argv = [exe, template], three stdin lines, JSON
     file out, stdout must not start with "Error"; the file must parse the way tapir/compute.py:24-44 parses it."""
