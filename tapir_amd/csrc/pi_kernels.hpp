@@ -42,32 +42,96 @@ struct ClassifyParams {
     const TreeOp* ops;            // the tree program: tips are visited in its order, and its PUSH / POP_MUL structure
     int32_t nops;                 // drives the parsimony pass that seeds the optimiser (ColumnScan::fitch_*)
     uint32_t* packed;             // [ceil(ntaxa/8)][ncols_total] out: 8 four-bit masks per word, program tip order
+    const int32_t* tip_taxon;     // [ntaxa] alignment row of the k-th tip of the program
 };
 
-// Per-column bookkeeping shared by the two load paths of classify_kernel.
+// Scalar loads of wave-uniform table entries.  classify_kernel also stores, so through plain pointers the compiler
+// cannot prove the tables invariant and fetches them with vector loads (one memory round trip per op, per lane).
+__device__ __forceinline__ int32_t scalar_load_i32(const int32_t* p) {   // p must be wave-uniform
+    int32_t r;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p));
+    return r;
+}
+typedef int SI8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ SI8 scalar_load_i32x8(const int32_t* p) {     // p wave-uniform and 32-byte aligned
+    SI8 r;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p));
+    return r;
+}
+
+// Per-column bookkeeping of classify_kernel, as its finishing code reads it.
 struct ColumnScan {
-    unsigned uni = 0, word = 0;
+    unsigned uni = 0;
     int resolved = 0, informative = 0;
-    // Fitch parsimony along the tree program: `set` is the state set of the subtree in the accumulator, `stk` the
-    // sets of the parked siblings (4 bits per level), `changes` the minimum number of substitutions so far.
-    unsigned set = 15u, changes = 0;
-    unsigned long long stk = 0;
-    __device__ __forceinline__ void fitch_join(unsigned x) {
-        const unsigned both = set & x;
-        changes += (both == 0u);
-        set = both ? both : (set | x);
+    unsigned changes = 0;   // Fitch parsimony: minimum number of substitutions on the tree
+};
+
+// Four consecutive columns at once: a thread's four state bytes of one taxon arrive as one dword, and every quantity
+// classify_kernel needs per tip is a per-byte operation on 4-bit masks (SWAR): 10 integer instructions per column and
+// tip instead of 30 with one ColumnScan per column, which made this byte kernel VALU-bound at 0.48 ms on C3 (its
+// 575 MB move in ~0.15 ms).
+//   * `set4` / `stk`: Fitch parsimony along the tree program -- the state set of the subtree in the accumulator (one
+//     byte per column) and the sets of the parked siblings (4 bits per level and column);
+//   * counters (resolved taxa, plain A/C/G/T cells, Fitch changes) accumulate one byte per column and are flushed
+//     into 32-bit totals every 64 tips.
+struct ColumnScan4 {
+    static constexpr uint32_t k01 = 0x01010101u, k0f = 0x0f0f0f0fu;
+    uint32_t uni4 = 0, set4 = k0f;
+    uint32_t res8 = 0, inf8 = 0, chg8 = 0;            // byte counters since the last flush
+    uint32_t word[4] = {0, 0, 0, 0};
+    int resolved[4] = {0, 0, 0, 0}, informative[4] = {0, 0, 0, 0};
+    unsigned changes[4] = {0, 0, 0, 0};
+    unsigned long long stk[4] = {0, 0, 0, 0};
+    // 0x01 in every byte whose low nibble (the only bits set) is nonzero / equals 15
+    static __device__ __forceinline__ uint32_t nonzero(uint32_t x) { return ((x + k0f) >> 4) & k01; }
+    static __device__ __forceinline__ uint32_t is15(uint32_t x) { return ((x + k01) >> 4) & k01; }
+    static __device__ __forceinline__ uint32_t spread(uint32_t b) { return (b << 4) - b; }   // 0x01 -> 0x0f per byte
+    __device__ __forceinline__ void flush() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            resolved[j] += (int)((res8 >> (8 * j)) & 0xffu);
+            informative[j] += (int)((inf8 >> (8 * j)) & 0xffu);
+            changes[j] += (chg8 >> (8 * j)) & 0xffu;
+        }
+        res8 = inf8 = chg8 = 0;
     }
-    __device__ __forceinline__ void fitch_push() { stk = (stk << 4) | set; set = 15u; }
-    __device__ __forceinline__ void fitch_pop() { const unsigned x = (unsigned)(stk & 15ull); stk >>= 4; fitch_join(x); }
-    __device__ __forceinline__ void tip(unsigned m, int k) {
-        m &= 15u;
-        m = m ? m : 15u;
-        const bool res = (m != 15u);
-        uni |= res ? m : 0u;
-        resolved += res;
-        informative += (__popc(m) == 1);
-        word |= m << (4 * (k & 7));
-        fitch_join(m);
+    __device__ __forceinline__ void fitch_join(uint32_t x4) {
+        const uint32_t both = set4 & x4;
+        const uint32_t empty = nonzero(both) ^ k01;
+        chg8 += empty;
+        set4 = both | ((set4 | x4) & spread(empty));
+    }
+    __device__ __forceinline__ void fitch_push() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stk[j] = (stk[j] << 4) | ((set4 >> (8 * j)) & 15u);
+        set4 = k0f;
+    }
+    __device__ __forceinline__ void fitch_pop() {
+        uint32_t x4 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x4 |= (uint32_t)(stk[j] & 15ull) << (8 * j); stk[j] >>= 4; }
+        fitch_join(x4);
+    }
+    // v: the state bytes of tip number k (program order) for the four columns
+    __device__ __forceinline__ void tip(uint32_t v, int k) {
+        uint32_t m4 = v & k0f;
+        m4 |= spread(nonzero(m4) ^ k01);              // code 0 (nothing allowed) reads as "anything": 15
+        const uint32_t res = is15(m4) ^ k01;          // resolved: not a gap / ? / N
+        uni4 |= m4 & spread(res);
+        res8 += res;
+        inf8 += nonzero(m4 & (m4 - k01)) ^ k01;       // exactly one bit set (m4 >= 1 in every byte: no borrow)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) word[j] |= ((m4 >> (8 * j)) & 15u) << (4 * (k & 7));
+        fitch_join(m4);
+        if ((k & 63) == 63) flush();   // <= 64 tip joins + <= 64 + 16 sibling joins per window: no byte overflows
+    }
+    __device__ __forceinline__ ColumnScan column(int j) const {   // after flush()
+        ColumnScan c;
+        c.uni = (uni4 >> (8 * j)) & 15u;
+        c.resolved = resolved[j];
+        c.informative = informative[j];
+        c.changes = changes[j];
+        return c;
     }
 };
 
@@ -131,76 +195,64 @@ __global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
     const bool full = (c0 + 4 <= hi);
     const bool aligned = full && ((reinterpret_cast<uintptr_t>(P.states) & 3u) == 0) && ((P.ncols_total & 3) == 0) &&
                          ((c0 & 3) == 0);
-    ColumnScan c[4];
-    if (aligned) {
-        int k = 0;
-        for (int ip = 0; ip < P.nops; ++ip) {
-            const int code = P.ops[ip].code;   // uniform -> scalar loads
-            if (code == OP_PUSH) {
+    const int n = full ? 4 : (int)(hi - c0);
+    const bool fast = __all(aligned);   // wave-uniform: only the last wave of a locus can have a ragged thread
+    ColumnScan4 c;
+    uint32_t buf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = 0;
+    for (int ip = 0; ip < P.nops; ++ip) {
+        const int code = scalar_load_i32(&P.ops[ip].code);
+        if (code == OP_PUSH) { c.fitch_push(); continue; }
+        if (code == OP_POP_MUL) { c.fitch_pop(); continue; }
+        if (code == OP_BRANCH) continue;
+        // The state dwords of eight tips are requested together when the first of them comes up: fetched one tip
+        // at a time (address from the op just read, value needed at once) every tip cost a full memory round trip
+        // and the kernel ran at 1.2 TB/s whatever its arithmetic.  (tip_taxon is padded to a multiple of 8.)
+        if ((k & 7) == 0) {
+            const SI8 tx = scalar_load_i32x8(P.tip_taxon + k);
+            const int t8[8] = {tx.s0, tx.s1, tx.s2, tx.s3, tx.s4, tx.s5, tx.s6, tx.s7};
+            if (fast) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c[j].fitch_push();
-                continue;
-            }
-            if (code == OP_POP_MUL) {
+                for (int i = 0; i < 8; ++i)
+                    buf[i] = *reinterpret_cast<const uint32_t*>(P.states + (int64_t)t8[i] * P.ncols_total + c0);
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c[j].fitch_pop();
-                continue;
-            }
-            if (code == OP_BRANCH) continue;
-            const int t = P.ops[ip].taxon;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(P.states + (int64_t)t * P.ncols_total + c0);
+                for (int i = 0; i < 8; ++i) {
+                    const uint8_t* row = P.states + (int64_t)t8[i] * P.ncols_total + c0;
+                    uint32_t w = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) c[j].tip((v >> (8 * j)) & 0xffu, k);
-            if ((k & 7) == 7 || k == P.ntaxa - 1) {
-                uint4 w = make_uint4(c[0].word, c[1].word, c[2].word, c[3].word);
-                *reinterpret_cast<uint4*>(P.packed + (int64_t)(k >> 3) * P.ncols_total + c0) = w;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[j].word = 0;
-            }
-            ++k;
-        }
-        uint8_t f[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) classify_finish(P, M, c0 + j, c[j], f[j]);
-        *reinterpret_cast<int4*>(P.nres + c0) = make_int4(c[0].informative, c[1].informative, c[2].informative, c[3].informative);
-        *reinterpret_cast<uint32_t*>(P.flag + c0) = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
-    } else {
-        const int n = full ? 4 : (int)(hi - c0);
-        int k = 0;
-        for (int ip = 0; ip < P.nops; ++ip) {
-            const int code = P.ops[ip].code;
-            if (code == OP_PUSH) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[j].fitch_push();
-                continue;
-            }
-            if (code == OP_POP_MUL) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) c[j].fitch_pop();
-                continue;
-            }
-            if (code == OP_BRANCH) continue;
-            const int t = P.ops[ip].taxon;
-            const uint8_t* row = P.states + (int64_t)t * P.ncols_total + c0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (j < n) c[j].tip(row[j], k);
-            if ((k & 7) == 7 || k == P.ntaxa - 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < n) P.packed[(int64_t)(k >> 3) * P.ncols_total + c0 + j] = c[j].word;
-                    c[j].word = 0;
+                    for (int j = 0; j < 4; ++j) if (j < n) w |= (uint32_t)row[j] << (8 * j);   // missing columns read as gaps
+                    buf[i] = w;
                 }
             }
-            ++k;
         }
+        uint32_t v = buf[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v = ((k & 7) == i) ? buf[i] : v;   // k is wave-uniform: scalar compares
+        c.tip(v, k);
+        if ((k & 7) == 7 || k == P.ntaxa - 1) {
+            if (fast) {
+                *reinterpret_cast<uint4*>(P.packed + (int64_t)(k >> 3) * P.ncols_total + c0) = make_uint4(c.word[0], c.word[1], c.word[2], c.word[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < n) P.packed[(int64_t)(k >> 3) * P.ncols_total + c0 + j] = c.word[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c.word[j] = 0;
+        }
+        ++k;
+    }
+    c.flush();
+    uint8_t f[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < n) classify_finish(P, M, c0 + j, c.column(j), f[j]);
+    if (fast) {
+        *reinterpret_cast<int4*>(P.nres + c0) = make_int4(c.informative[0], c.informative[1], c.informative[2], c.informative[3]);
+        *reinterpret_cast<uint32_t*>(P.flag + c0) = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
+    } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (j < n) {
-                uint8_t f;
-                classify_finish(P, M, c0 + j, c[j], f);
-                P.nres[c0 + j] = c[j].informative;
-                P.flag[c0 + j] = f;
-            }
+            if (j < n) { P.nres[c0 + j] = c.informative[j]; P.flag[c0 + j] = f[j]; }
         }
     }
 }

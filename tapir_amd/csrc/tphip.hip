@@ -250,6 +250,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     std::vector<int32_t> tip_taxon;
     for (const TreeOp& op : p->prog.ops) if (op.code <= OP_TIP_MUL) tip_taxon.push_back(op.taxon);
     p->nwords = (int32_t)((tip_taxon.size() + 7) / 8);
+    while (tip_taxon.size() % 8) tip_taxon.push_back(tip_taxon.back());   // classify_kernel reads it eight at a time
     if (e == hipSuccess) e = p->d_tip_taxon.upload(tip_taxon);
     if (e == hipSuccess) e = p->d_op_node.upload(p->prog.op_node);
     if (e == hipSuccess && !cat.empty()) e = p->d_cat.upload(cat);
@@ -448,6 +449,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     C.chrono_length = p->prog.chrono_length;
     C.ops = p->d_ops.p; C.nops = (int32_t)p->prog.ops.size();
     C.packed = (uint32_t*)((char*)ws + p->ws_packed);
+    C.tip_taxon = p->d_tip_taxon.p;
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
         compact_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
