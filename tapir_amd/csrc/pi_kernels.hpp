@@ -257,28 +257,33 @@ __global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
     }
 }
 
-// One workgroup per locus: stable compaction of the columns that still need the optimiser.
-__global__ __launch_bounds__(256) void compact_kernel(const uint8_t* __restrict__ flag, const int64_t* __restrict__ locus_offsets,
-                                                      int32_t* __restrict__ work_cols, int32_t* __restrict__ work_count) {
-    __shared__ int wave_tot[4];
+// One workgroup per locus: stable compaction of the columns that still need the optimiser.  The loop is a chain of
+// barriers, so its time is the number of rounds: long loci get 1024 threads (C3: 49 rounds per locus instead of 196),
+// short ones 256.
+template <int kCompactBlock>
+__global__ __launch_bounds__(kCompactBlock) void compact_kernel(const uint8_t* __restrict__ flag, const int64_t* __restrict__ locus_offsets,
+                                                                int32_t* __restrict__ work_cols, int32_t* __restrict__ work_count) {
+    constexpr int kWaves = kCompactBlock / 64;
+    __shared__ int wave_tot[kWaves];
     __shared__ int running;
     const int locus = blockIdx.x;
     const int64_t lo = locus_offsets[locus], hi = locus_offsets[locus + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) running = 0;
     __syncthreads();
-    for (int64_t base = lo; base < hi; base += 256) {
+    for (int64_t base = lo; base < hi; base += kCompactBlock) {
         const int64_t col = base + threadIdx.x;
         const bool want = (col < hi) && (flag[col] == TPHIP_FLAG_OK);
         const unsigned long long bal = __ballot(want);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
         if (lane == 0) wave_tot[wave] = __popcll(bal);
         __syncthreads();
-        int off = running;
-        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        int off = running, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) { off += (w < wave) ? wave_tot[w] : 0; tot += wave_tot[w]; }
         if (want) work_cols[lo + off + before] = (int32_t)col;
         __syncthreads();
-        if (threadIdx.x == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        if (threadIdx.x == 0) running += tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) work_count[locus] = running;

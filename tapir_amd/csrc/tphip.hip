@@ -452,7 +452,8 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     C.tip_taxon = p->d_tip_taxon.p;
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
-        compact_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
+        if (p->max_locus_cols > 2048) compact_kernel<1024><<<dim3((unsigned)p->nloci), dim3(1024), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
+        else compact_kernel<256><<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
         scan_counts_kernel<<<dim3(1), dim3(1024), 0, st>>>(work_count, p->nloci, p->site_chunk_cols, (int64_t*)((char*)ws + p->ws_work_prefix),
                                                            (int64_t*)((char*)ws + p->ws_slice_prefix));
     }
