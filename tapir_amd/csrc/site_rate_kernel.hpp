@@ -640,6 +640,9 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         int next = begin + kSiteBlock;  // wave-uniform: first work index not yet handed to a lane
         bool done = (begin + lane >= end);
         int64_t col = work[done ? begin : begin + lane];
+        // the next 64 candidates of the work list, one per lane, requested an evaluation before a refill needs them: the
+        // refill then costs one memory round trip (the column's packed tips and start value), not two
+        int32_t cand = work[next + lane < end ? next + lane : end - 1];
         uint32_t pk[NW > 0 ? NW : 1] = {0};
 #pragma unroll
         for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
@@ -764,8 +767,9 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
             if (next < end) {
                 const int rank = __popcll(free_mask & ((1ull << lane) - 1ull));
                 const int idx = next + rank;
+                const int32_t picked = __shfl(cand, rank);   // = work[next + rank]
                 if (done && idx < end) {
-                    col = work[idx];
+                    col = picked;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
                     if constexpr (NW == kStreamWords) pk[0] = P.packed[col];
@@ -774,6 +778,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     done = false;
                 }
                 next += __popcll(free_mask);
+                if (next < end) cand = work[next + lane < end ? next + lane : end - 1];
             } else if (free_mask == ~0ull) {
                 break;  // segment exhausted and every lane finished
             }
