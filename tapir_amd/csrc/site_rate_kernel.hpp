@@ -227,7 +227,7 @@ __device__ __forceinline__ void cherry_over(const ModelRegs& R, const double* __
 }
 
 // acc <- P(t s) * acc with derivatives (internal branch)
-__device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* __restrict__ etab, double ts, double f, Partial& p) {
+__device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* __restrict__ etab, double ts, Partial& p) {
     double w0[4], w1[4], w2[4];
     w0[0] = fma(R.pi[3], p.v[3], fma(R.pi[2], p.v[2], fma(R.pi[1], p.v[1], R.pi[0] * p.v[0])));
     w1[0] = fma(R.pi[3], p.d1[3], fma(R.pi[2], p.d1[2], fma(R.pi[1], p.d1[1], R.pi[0] * p.d1[0])));
@@ -239,12 +239,12 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* _
         w1[k] = fma(Ir[3], p.d1[3], fma(Ir[2], p.d1[2], fma(Ir[1], p.d1[1], Ir[0] * p.d1[0])));
         w2[k] = fma(Ir[3], p.d2[3], fma(Ir[2], p.d2[2], fma(Ir[1], p.d2[1], Ir[0] * p.d2[0])));
     }
-    const double z0 = w0[0] * f, z1 = w1[0] * f, z2 = w2[0] * f;  // eigenvalue 0: e = 1
+    const double z0 = w0[0], z1 = w1[0], z2 = w2[0];  // eigenvalue 0: e = 1
     double a[3], b[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         double x = R.lam[k] * ts;
-        double e = (kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x)) * f;
+        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
         a[k] = e * w0[k + 1];
         double ew1 = e * w1[k + 1], ew2 = e * w2[k + 1];
         b[k] = fma(x, a[k], ew1);
@@ -266,20 +266,25 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* _
 }
 
 // Rescaling for deep trees / hundreds of taxa: when the largest component of the running partial is below 2^-256
-// the NEXT message it meets is multiplied by 2^-e (returned here, 1.0 otherwise) and e is added to `scale`.
-// Everything downstream is linear in that message, so folding the factor into it (4 multiplies on a tip's
-// U^-1 row, 6 on a branch) rescales value and both derivatives without a branch and without touching the 12
-// accumulator registers (a conditional in-place multiply made the compiler copy all of them on every op).
-// Partials are non-negative, so their high words order like unsigned integers.
-__device__ __forceinline__ double rescale_factor(const Partial& p, int& scale) {
+// the partial (value and both derivatives) is multiplied by 2^-e and e is added to `scale` -- exact, and everything
+// downstream is linear in it.  The test runs before every TIP_MUL and BRANCH; it is 4 integer instructions and a
+// ballot (partials are non-negative, so their high words order like unsigned integers), and the multiplication
+// sits behind a wave-uniform branch that is almost never taken: 12 in-place multiplies there instead of 4-6
+// multiplies and 6 more integer instructions folded into every message.
+__device__ __forceinline__ void rescale_if_needed(Partial& p, int& scale) {
     const unsigned h0 = (unsigned)__double2hiint(p.v[0]), h1 = (unsigned)__double2hiint(p.v[1]);
     const unsigned h2 = (unsigned)__double2hiint(p.v[2]), h3 = (unsigned)__double2hiint(p.v[3]);
     const unsigned mx = max(max(h0, h1), max(h2, h3));
+    const unsigned kOne = 1u << 20;                      // smallest normal high word
     const unsigned kLow = (unsigned)(1023 - 256) << 20;  // 2^-256
-    const bool need = (mx < kLow && mx >= (1u << 20));   // below 2^-256 and still a normal number
-    const int e = need ? (int)(mx >> 20) - 1023 : 0;
-    scale += e;
-    return __hiloint2double((1023 - e) << 20, 0);        // 2^-e
+    const bool need = (mx - kOne) < (kLow - kOne);       // below 2^-256 and still a normal number
+    if (__any(need)) {
+        const int e = need ? (int)(mx >> 20) - 1023 : 0;
+        scale += e;
+        const double f = __hiloint2double((1023 - e) << 20, 0);   // 2^-e
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mul_into(p.v[i], f); mul_into(p.d1[i], f); mul_into(p.d2[i], f); }
+    }
 }
 
 // Hand-issued scalar load of one TreeOp (16 bytes) and its explicit wait; see evaluate_column.
@@ -429,8 +434,8 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
                 tip_message_over(R, etab, wv, op.t * s, acc);
             } else {
                 Partial m;
-                const double f = rescale_factor(acc, scale);
-                const double wv[4] = {w[0] * f, w[1] * f, w[2] * f, w[3] * f};
+                rescale_if_needed(acc, scale);
+                const double wv[4] = {w[0], w[1], w[2], w[3]};
                 tip_message(R, etab, wv, op.t * s, m);
                 partial_mul(acc, m);
             }
@@ -454,8 +459,8 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
             }
             partial_mul(acc, m);
         } else if (op.code == OP_BRANCH) {
-            const double f = rescale_factor(acc, scale);
-            branch_apply(R, etab, op.t * s, f, acc);
+            rescale_if_needed(acc, scale);
+            branch_apply(R, etab, op.t * s, acc);
         } else {  // OP_PUSH: park the finished sibling; the TIP_SET that always follows overwrites the accumulator
             double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
 #pragma unroll
