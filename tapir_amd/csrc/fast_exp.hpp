@@ -80,8 +80,9 @@ __device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restr
     q = fma(q, r, 1.0);
     q = q * r;                                      // q = exp(r) - 1
     const double p = fma(T, q, T);                  // in [0.99, 2.0)
-    const int hi = __double2hiint(p) + (int)((unsigned)(k >> 6) << 20);
-    return __hiloint2double(hi, __double2loint(p));
+    // 2^n through v_ldexp_f64 (shift + ldexp) rather than integer arithmetic on the exponent field (shift, mask,
+    // add): same bits (n >= -1022 after the clamp), one instruction fewer per exp, C3 site rates -1 % (A/B on one box)
+    return ldexp(p, k >> 6);
 }
 
 }  // namespace tphip
