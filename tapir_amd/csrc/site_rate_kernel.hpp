@@ -6,23 +6,26 @@
 // parsimony rate computed by classify_kernel (same maximum, one evaluation fewer).
 //
 // Mapping to CDNA4
-//   * one alignment column per lane, one wavefront per workgroup, all of one locus, so the locus'
-//     eigen-system (32 doubles) and the tree program are wave-uniform: they live in SGPRs / the scalar
-//     cache and enter the FP64 VALU instructions as scalar operands;
-//   * the traversal is the uniform op stream of tree_program.hpp -- no lane divergence inside a likelihood
-//     evaluation; lanes differ only in how many Newton steps they need, and a lane whose column has
-//     converged immediately takes the next column of the wave's work slice (lane refill), so the wave
-//     keeps 64 live columns until its slice runs dry;
-//   * the next op and the next tip's state byte are fetched one op ahead (scalar load / global byte load
-//     in flight under the current op's ~10^3 cycles of FP64 work);
-//   * the running partial (value, d/du, d2/du2 of the 4 conditional likelihoods; u = log siteRate) is 12
-//     doubles in VGPRs; parked siblings go to an LDS stack laid out [slot][component][lane] so every
-//     ds_read/write_b64 is a conflict-free 512-B row;
-//   * tips: the per-mask vectors U^-1 * tip(mask) are a 16x4 table in LDS built once per workgroup;
+//   * one alignment column per lane, one wavefront per workgroup, all of one locus, so the locus' eigen-system
+//     (31 doubles) and the tree program are wave-uniform.  The program arrives by hand-issued scalar loads two ops
+//     ahead; the model sits in (lane-replicated) VGPRs, loaded through LDS: 62 SGPRs of model do not fit beside the
+//     op pipeline and the pointers, and the spills cost more issue slots than the registers do;
+//   * the traversal is the uniform op stream of tree_program.hpp (fused form: the two tips of a cherry on equally long
+//     branches are one CHERRY op sharing their exponentials) -- no lane divergence inside a likelihood evaluation;
+//     lanes differ only in how many Newton steps they need, and a lane whose column has converged immediately takes
+//     the next column of the wave's work share (lane refill), so the wave keeps 64 live columns until it runs dry;
+//   * a column's tip states are 4-bit masks packed 8 per word by classify_kernel: in registers for up to 64 tips,
+//     streamed one word ahead beyond; the Newton iterations never touch the alignment again;
+//   * the running partial (value, d/du, d2/du2 of the 4 conditional likelihoods; u = log siteRate) is 12 doubles
+//     in VGPRs, updated IN PLACE (tied-operand asm, see mul_into): no register copies in the op loop; parked
+//     siblings go to an LDS stack laid out [slot][component][lane] so every ds_read/write_b64 is a conflict-free
+//     512-B row;
+//   * tips: the per-mask vectors U^-1 * tip(mask) are a 16x4 table in LDS built once per locus segment;
 //   * constant / flat columns never reach this kernel: classify_kernel answers them in closed form and
 //     compact_kernel packs the remaining columns so that lanes are not idle beside them;
-//   * MFMA is deliberately not used: the work is 4x4 mat-vecs with a different matrix (rate) per lane.
-//     The kernel is FP64-VALU/transcendental bound; its HBM traffic is ntaxa+24 bytes per column.
+//   * MFMA is not used: every lane's transition matrix is its own; the shared eigenvector products would need a
+//     lane = (column, state) layout, and on gfx950 FP64 MFMA shares the FP64 VALU's rate and issue slot (measured).
+//     The kernel is FP64-VALU bound; its HBM traffic is ntaxa/2 + 29 bytes per optimised column.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
