@@ -419,38 +419,20 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
         SOp raw = sop_issue(ops + ((ip + 2 < last) ? ip + 2 : last));
         unsigned st_nxt = 15u;
         if constexpr (NW == 0) {
-            if (nxt.code <= OP_TIP_MUL) st_nxt = load_state(P, nxt.taxon, col);
+            if ((nxt.code & OP_CODE_MASK) <= OP_TIP_MUL) st_nxt = load_state(P, nxt.taxon, col);
         }
-        if (op.code <= OP_TIP_MUL) {
-            unsigned mask;
-            if constexpr (NW != 0) {
-                mask = next_mask();   // zero codes were turned into 15 when the word was packed
-            } else {
-                mask = st & 15u;
-                mask = mask ? mask : 15u;
+        const int code = op.code & OP_CODE_MASK;   // the fused stream ORs OP_PUSH_BEFORE / OP_POP_AFTER into the code
+        auto park = [&]() {     // PUSH: the finished sibling goes to the LDS stack; the TIP_SET / CHERRY that always
+            double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;   // follows overwrites the accumulator
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                slot[(i)*kSiteBlock] = acc.v[i];
+                slot[(4 + i) * kSiteBlock] = acc.d1[i];
+                slot[(8 + i) * kSiteBlock] = acc.d2[i];
             }
-            const double* w = wtab + mask * 4;
-            if (op.code == OP_TIP_SET) {
-                // A subtree starts here (program start, or right after a PUSH: tree_program.hpp emits no other
-                // TIP_SET): the tip's message IS the new accumulator -- no product with an identity, no rescaling.
-                const double wv[4] = {w[0], w[1], w[2], w[3]};
-                tip_message_over(R, etab, wv, op.t * s, acc);
-            } else {
-                Partial m;
-                rescale_if_needed(acc, scale);
-                const double wv[4] = {w[0], w[1], w[2], w[3]};
-                tip_message(R, etab, wv, op.t * s, m);
-                partial_mul(acc, m);
-            }
-        } else if (NW != 0 && op.code == OP_CHERRY) {   // fused stream (packed paths only)
-            const unsigned mask1 = next_mask();
-            const unsigned mask2 = next_mask();
-            const double* w1 = wtab + mask1 * 4;
-            const double* w2 = wtab + mask2 * 4;
-            const double wa[4] = {w1[0], w1[1], w1[2], w1[3]};
-            const double wb[4] = {w2[0], w2[1], w2[2], w2[3]};
-            cherry_over(R, etab, wa, wb, op.t * s, acc);
-        } else if (op.code == OP_POP_MUL) {
+            ++sp;
+        };
+        auto pop_mul = [&]() {  // POP_MUL: acc *= parked sibling
             Partial m;
             --sp;
             const double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
@@ -461,18 +443,46 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
                 m.d2[i] = slot[(8 + i) * kSiteBlock];
             }
             partial_mul(acc, m);
-        } else if (op.code == OP_BRANCH) {
+        };
+        if (code == OP_BRANCH) {
             rescale_if_needed(acc, scale);
             branch_apply(R, etab, op.t * s, acc);
-        } else {  // OP_PUSH: park the finished sibling; the TIP_SET that always follows overwrites the accumulator
-            double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                slot[(i)*kSiteBlock] = acc.v[i];
-                slot[(4 + i) * kSiteBlock] = acc.d1[i];
-                slot[(8 + i) * kSiteBlock] = acc.d2[i];
+            if (op.code & OP_POP_AFTER) pop_mul();
+        } else if (code <= OP_TIP_MUL) {
+            unsigned mask;
+            if constexpr (NW != 0) {
+                mask = next_mask();   // zero codes were turned into 15 when the word was packed
+            } else {
+                mask = st & 15u;
+                mask = mask ? mask : 15u;
             }
-            ++sp;
+            const double* w = wtab + mask * 4;
+            if (code == OP_TIP_SET) {
+                // A subtree starts here (program start, or right after a PUSH: tree_program.hpp emits no other
+                // TIP_SET): the tip's message IS the new accumulator -- no product with an identity, no rescaling.
+                if (op.code & OP_PUSH_BEFORE) park();
+                const double wv[4] = {w[0], w[1], w[2], w[3]};
+                tip_message_over(R, etab, wv, op.t * s, acc);
+            } else {
+                Partial m;
+                rescale_if_needed(acc, scale);
+                const double wv[4] = {w[0], w[1], w[2], w[3]};
+                tip_message(R, etab, wv, op.t * s, m);
+                partial_mul(acc, m);
+            }
+        } else if (NW != 0 && code == OP_CHERRY) {   // fused stream (packed paths only)
+            if (op.code & OP_PUSH_BEFORE) park();
+            const unsigned mask1 = next_mask();
+            const unsigned mask2 = next_mask();
+            const double* w1 = wtab + mask1 * 4;
+            const double* w2 = wtab + mask2 * 4;
+            const double wa[4] = {w1[0], w1[1], w1[2], w1[3]};
+            const double wb[4] = {w2[0], w2[1], w2[2], w2[3]};
+            cherry_over(R, etab, wa, wb, op.t * s, acc);
+        } else if (code == OP_POP_MUL) {
+            pop_mul();
+        } else {  // OP_PUSH
+            park();
         }
         sop_wait(raw);
         op = nxt;

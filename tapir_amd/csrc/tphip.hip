@@ -370,7 +370,7 @@ int tphip_plan_op_counts(const tphip_plan* p, int32_t* counts) {
 int32_t tphip_plan_cherry_count(const tphip_plan* p) {
     if (!p) return 0;
     int32_t n = 0;
-    for (const TreeOp& op : p->prog.fused_ops) n += (op.code == OP_CHERRY);
+    for (const TreeOp& op : p->prog.fused_ops) n += ((op.code & OP_CODE_MASK) == OP_CHERRY);
     return n;
 }
 

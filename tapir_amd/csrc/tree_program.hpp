@@ -25,6 +25,11 @@ namespace tphip {
 
 enum : int32_t { OP_TIP_SET = 0, OP_TIP_MUL = 1, OP_BRANCH = 2, OP_PUSH = 3, OP_POP_MUL = 4,
                  OP_CHERRY = 5 };  // fused stream only: TIP_SET + TIP_MUL on equally long branches
+// fused stream only, OR-ed into the code: the interpreter pays ~35 scalar instructions and several branches per op,
+// so the two cheap stack ops ride on their neighbours
+enum : int32_t { OP_CODE_MASK = 0xff,
+                 OP_PUSH_BEFORE = 0x100,   // on TIP_SET / CHERRY: park the accumulator first (the PUSH that preceded it)
+                 OP_POP_AFTER = 0x200 };   // on BRANCH: multiply the parked sibling in afterwards (the POP_MUL that followed)
 
 struct TreeOp {
     int32_t code;
@@ -150,14 +155,22 @@ inline std::string build_tree_program(int32_t ntaxa, int32_t nnodes, const int32
     }
     if (!pushed.empty()) return "internal error: unbalanced PUSH";
     out->fused_ops.clear();
+    int32_t pending = 0;
     for (size_t i = 0; i < out->ops.size(); ++i) {
         const TreeOp& a = out->ops[i];
-        if (a.code == OP_TIP_SET && i + 1 < out->ops.size() && out->ops[i + 1].code == OP_TIP_MUL &&
-            out->ops[i + 1].t == a.t) {
-            out->fused_ops.push_back({OP_CHERRY, a.taxon, a.t});
+        const bool has_next = i + 1 < out->ops.size();
+        if (a.code == OP_PUSH && has_next && out->ops[i + 1].code == OP_TIP_SET) {
+            pending = OP_PUSH_BEFORE;   // carried by the TIP_SET / CHERRY that follows
+        } else if (a.code == OP_TIP_SET && has_next && out->ops[i + 1].code == OP_TIP_MUL && out->ops[i + 1].t == a.t) {
+            out->fused_ops.push_back({OP_CHERRY | pending, a.taxon, a.t});
+            pending = 0;
+            ++i;
+        } else if (a.code == OP_BRANCH && has_next && out->ops[i + 1].code == OP_POP_MUL) {
+            out->fused_ops.push_back({OP_BRANCH | OP_POP_AFTER, a.taxon, a.t});
             ++i;
         } else {
-            out->fused_ops.push_back(a);
+            out->fused_ops.push_back({a.code | pending, a.taxon, a.t});
+            pending = 0;
         }
     }
     return "";
