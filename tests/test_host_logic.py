@@ -617,3 +617,52 @@ def test_nexus_sequential_wrapping_and_matchchar(tmp_path):
     p.write_text("#NEXUS\nBEGIN DATA;\nDIMENSIONS NTAX=2 NCHAR=4;\nFORMAT DATATYPE=DNA;\nMATRIX\na ACGT\nb ACG\n;\nEND;\n")
     with pytest.raises(nexus.NexusError):
         nexus.read_states(str(p))
+
+
+def test_fused_tree_program_expands_to_the_plain_one(tmp_path):
+    """tree_program.hpp (host side, compiled with g++): the fused op stream site_rate_kernel interprets -- CHERRY for
+    TIP_SET + TIP_MUL on equally long branches, PUSH / POP_MUL riding as flags on their neighbours -- must expand to
+    exactly the plain stream classify_kernel and the likelihood kernels read."""
+    import subprocess
+    from tapir_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tree_program_dump")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "tapir_amd", "csrc"),
+                           os.path.join(root, "tests", "native", "tree_program_dump.cpp"), "-o", exe])
+    TIP_SET, TIP_MUL, BRANCH, PUSH, POP_MUL, CHERRY = range(6)
+    PUSH_BEFORE, POP_AFTER = 0x100, 0x200
+    for ntaxa, seed, perturb in [(64, synth.WORKLOAD_SEED["C3"], False), (16, synth.WORKLOAD_SEED["C2"], False), (37, 5, True)]:
+        tree_root, names = synth.yule_tree(ntaxa, seed)
+        pin = synth.plan_inputs(tree_root, names)
+        parent, blen, leaf = np.asarray(pin["parent"]), np.asarray(pin["blen"], dtype=np.float64).copy(), np.asarray(pin["leaf"])
+        if perturb:   # a non-ultrametric tree: most cherries lose their equal branch lengths
+            blen *= 1.0 + 0.3 * np.random.default_rng(1).random(len(blen))
+        text = "%d %d\n" % (ntaxa, len(parent)) + "".join("%d %.17g %d\n" % (parent[i], blen[i], leaf[i]) for i in range(len(parent)))
+        out = subprocess.run([exe], input=text, capture_output=True, text=True, check=True).stdout.split("\n")
+        plain = [(int(a), int(b), float(c)) for tag, a, b, c in (l.split() for l in out if l.startswith("plain"))]
+        fused = [(int(a), int(b), float(c)) for tag, a, b, c in (l.split() for l in out if l.startswith("fused"))]
+        tips = [op for op in plain if op[0] <= TIP_MUL]
+        expanded, k = [], 0
+        for code, taxon, t in fused:
+            base, flags = code & 0xff, code & ~0xff
+            if flags & PUSH_BEFORE:
+                assert base in (TIP_SET, CHERRY)
+                expanded.append((PUSH, 0, 0.0))
+            if base == CHERRY:
+                assert tips[k][0] == TIP_SET and tips[k + 1][0] == TIP_MUL and tips[k][2] == tips[k + 1][2] == t
+                expanded += [tips[k], tips[k + 1]]
+                k += 2
+            else:
+                expanded.append((base, taxon, t))
+                k += base <= TIP_MUL
+            if flags & POP_AFTER:
+                assert base == BRANCH
+                expanded.append((POP_MUL, 0, 0.0))
+        assert expanded == plain
+        assert not any(code == PUSH or code == POP_MUL for code, _, _ in fused)   # every one of them found a neighbour
+        ncherry = sum(1 for code, _, _ in fused if code & 0xff == CHERRY)
+        if not perturb:
+            assert ncherry == sum(1 for i in range(len(plain) - 1)
+                                  if plain[i][0] == TIP_SET and plain[i + 1][0] == TIP_MUL and plain[i][2] == plain[i + 1][2]) > 0
+            if ntaxa == 64:
+                assert ncherry == 21 and len(fused) == 105
