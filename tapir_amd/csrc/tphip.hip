@@ -118,6 +118,7 @@ struct tphip_plan {
     int32_t num_cus = 256;
     int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
     int32_t site_persistent = 1;
+    int32_t site_grid_mult = 1;   // persistent grid = resident waves x this (see plan creation)
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev;  // 4 events per slot: site start/stop, pi start/stop
@@ -340,6 +341,17 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
         if (const char* e3 = getenv("TPHIP_SITE_PERSISTENT")) p->site_persistent = (e3[0] == '1');
         if (const char* e2 = getenv("TPHIP_SITE_WAVES")) { long v = atol(e2); if (v >= 1) p->site_waves = (int32_t)v; }  // tuning knob
+        // Shares twice as many as resident waves when they are long and lie inside one locus (few, long loci: C3):
+        // loci differ in evaluations per column, equal column counts are then unequal work, and the dispatcher
+        // evens that out by handing the second half of the shares to whichever waves finish first (C3 8.6 -> 7.5 ms).
+        // Many short loci per share average the differences out themselves (C4: 2x costs 2.5 %), short shares only
+        // add drains.
+        {
+            const int64_t share = ncols / std::max(1, p->site_waves);
+            const int64_t avg_locus = ncols / std::max<int64_t>(1, d->nloci);
+            p->site_grid_mult = (p->site_persistent && share >= 2000 && avg_locus >= 4 * share) ? 2 : 1;
+            if (const char* e7 = getenv("TPHIP_SITE_GRID_MULT")) { long v = atol(e7); if (v >= 1 && v <= 16) p->site_grid_mult = (int32_t)v; }
+        }
     }
     // workspace layout
     size_t off = 0;
@@ -474,7 +486,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_site_chunks > 0) {
-        const dim3 grid((unsigned)(p->site_persistent ? p->site_waves : p->n_site_chunks)), block(kSiteBlock);
+        const dim3 grid((unsigned)(p->site_persistent ? p->site_waves * p->site_grid_mult : p->n_site_chunks)), block(kSiteBlock);
         // packed tip states: in registers up to 64 tips, streamed one word ahead beyond (site_rate_kernel.hpp)
         const char* fb = getenv("TPHIP_FORCE_BYTE_PATH");  // test/tuning knob: exercise the NW = 0 kernel on any tree
         const bool byte_path = (fb && fb[0] == '1');
