@@ -77,7 +77,9 @@ struct SiteParams {
     const int64_t* work_prefix;    // [nloci+1] exclusive scan of work_count (scan_counts_kernel)
     const int64_t* slice_prefix;   // [nloci+1] exclusive scan of the per-locus slice counts (non-persistent mode)
     int64_t nloci;
-    int32_t persistent;            // 1: grid = resident waves, equal shares of the global work list; 0: grid = slices
+    int32_t persistent;            // 1: grid = resident waves (x grid multiplier), shares of the global work list; 0: grid = slices
+    int32_t first_round;           // persistent: the first `first_round` workgroups (one per resident wave) share
+    double first_fraction;         //   this fraction of the work equally, the others the rest (see site_rate_kernel)
     int32_t ncat;                  // > 1: discrete rate mixture on top of the site rate (tphip_plan_desc.ncat)
     const double* cat;             // [2 * ncat]: category rate multipliers, then log weights
     double* rate;
@@ -611,8 +613,19 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
     int64_t g0, g1, lo_l;
     if (P.persistent) {
         const int64_t total = P.work_prefix[P.nloci];
-        g0 = (int64_t)blockIdx.x * total / gridDim.x;
-        g1 = (int64_t)(blockIdx.x + 1) * total / gridDim.x;
+        // Share boundaries: with more shares than resident waves the first round (one share per resident wave) gets
+        // `first_fraction` of the work and the later, smaller shares are what the dispatcher balances the waves'
+        // finishing times with (equal shares when first_fraction = first_round / gridDim.x).
+        auto boundary = [&](unsigned b) -> int64_t {
+            const unsigned R = (unsigned)P.first_round, N = gridDim.x;
+            if (R >= N) return (int64_t)b * total / N;
+            const double f = (b <= R) ? P.first_fraction * (double)b / (double)R
+                                      : P.first_fraction + (1.0 - P.first_fraction) * (double)(b - R) / (double)(N - R);
+            const int64_t g = (int64_t)(f * (double)total);
+            return b >= N ? total : (g < total ? g : total);
+        };
+        g0 = boundary(blockIdx.x);
+        g1 = boundary(blockIdx.x + 1);
         if (g0 >= g1) return;
         // first locus of this share: the last l with prefix[l] <= g0 (binary search, wave-uniform)
         int64_t hi_l = P.nloci;

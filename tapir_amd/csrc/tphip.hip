@@ -119,6 +119,7 @@ struct tphip_plan {
     int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
     int32_t site_persistent = 1;
     int32_t site_grid_mult = 1;   // persistent grid = resident waves x this (see plan creation)
+    double site_first_fraction = 0.0;   // share of the work the first round of shares takes (0 = equal shares)
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev;  // 4 events per slot: site start/stop, pi start/stop
@@ -341,20 +342,18 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
         if (const char* e3 = getenv("TPHIP_SITE_PERSISTENT")) p->site_persistent = (e3[0] == '1');
         if (const char* e2 = getenv("TPHIP_SITE_WAVES")) { long v = atol(e2); if (v >= 1) p->site_waves = (int32_t)v; }  // tuning knob
-        // Shares twice as many as resident waves when they are long and lie inside one locus (few, long loci: C3):
-        // loci differ in evaluations per column, equal column counts are then unequal work, and the dispatcher
-        // evens that out by handing the second half of the shares to whichever waves finish first (C3 8.6 -> 7.5 ms).
-        // Many short loci per share average the differences out themselves (C4: 2x costs 2.5 %), short shares only
-        // add drains.
+        // Share sizes of the persistent grid.  Equal shares (one per resident wave) are equal column counts, not equal
+        // work: loci differ in evaluations per column, and with 5-7 resident waves per CU (deep LDS stacks) a wave that
+        // shares its SIMD runs slower than one that does not.  So the resident waves' first shares take 85 % of the
+        // batch and the rest is cut into twice as many small shares that the dispatcher hands to whichever waves
+        // finish first: site_rate_kernel C3 8.4 -> 7.0 ms, C4 share 9.8 -> 9.2, C5 share 20.9 -> 17.1.  Batches whose
+        // shares are short anyway only gain drains (2.2 M columns in 2200 loci: +3.5 %): they keep equal shares.
         {
             const int64_t share = ncols / std::max(1, p->site_waves);
-            const int64_t avg_locus = ncols / std::max<int64_t>(1, d->nloci);
-            p->site_grid_mult = (p->site_persistent && share >= 2000 && avg_locus >= 4 * share) ? 2 : 1;
-            // Deep LDS stacks leave 6 (or 5, 7) resident waves per CU: some SIMDs hold two waves, some one, a wave
-            // that shares its SIMD runs slower, and equal shares finish unevenly -- four times as many shares let the
-            // dispatcher even that out (C5: 20.7 -> 19.6 ms)
-            const int per_cu_now = p->site_waves / std::max(1, p->num_cus);
-            if (p->site_persistent && (per_cu_now % 4) != 0 && share >= 1200) p->site_grid_mult = 4;
+            const bool uneven = p->site_persistent && share >= 1500;
+            p->site_grid_mult = uneven ? 3 : 1;
+            p->site_first_fraction = uneven ? 0.85 : 0.0;
+            if (const char* e8 = getenv("TPHIP_SITE_FIRST_FRACTION")) p->site_first_fraction = atof(e8);
             if (const char* e7 = getenv("TPHIP_SITE_GRID_MULT")) { long v = atol(e7); if (v >= 1 && v <= 16) p->site_grid_mult = (int32_t)v; }
         }
     }
@@ -487,6 +486,8 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     S.persistent = p->site_persistent;
+    S.first_round = p->site_waves;
+    S.first_fraction = (p->site_first_fraction > 0.0) ? p->site_first_fraction : 1.0 / (double)p->site_grid_mult;
     S.ncat = p->ncat; S.cat = p->d_cat.p;
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
@@ -871,7 +872,7 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
     E.S.chunk_cols = p->site_chunk_cols;
     E.S.packed = nullptr; E.S.nwords = 0;
-    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
+    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
     E.S.flag = nullptr; E.S.eval_counter = nullptr;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
