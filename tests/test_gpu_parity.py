@@ -338,6 +338,42 @@ def test_fused_cherries_follow_the_branch_lengths(oracle):
     assert counts == [21, 20]
 
 
+def test_results_do_not_depend_on_how_the_work_list_is_shared_out(monkeypatch):
+    """A column's result depends on the column alone: whatever the persistent grid's share boundaries (resident-wave
+    count, grid multiplier, first-round fraction) or the small-batch slice length, every output must be bit-identical --
+    which also proves that the shares cover each optimiser column exactly once."""
+    engine = _engine()
+    from tapir_amd import synth
+    d = synth.simulate(7, 3001, 24, 77)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    off = d["locus_offsets"].copy()
+    off[3] = off[2]          # an empty locus in the middle
+    settings = [dict(),
+                dict(TPHIP_SITE_PERSISTENT="1", TPHIP_SITE_WAVES="37"),
+                dict(TPHIP_SITE_PERSISTENT="1", TPHIP_SITE_WAVES="16", TPHIP_SITE_GRID_MULT="3", TPHIP_SITE_FIRST_FRACTION="0.8"),
+                dict(TPHIP_SITE_PERSISTENT="1", TPHIP_SITE_WAVES="5", TPHIP_SITE_GRID_MULT="7", TPHIP_SITE_FIRST_FRACTION="0.33"),
+                dict(TPHIP_SITE_PERSISTENT="1", TPHIP_SITE_WAVES="2048", TPHIP_SITE_GRID_MULT="2", TPHIP_SITE_FIRST_FRACTION="0.999"),
+                dict(TPHIP_SITE_PERSISTENT="0", TPHIP_SITE_CHUNK="64"),
+                dict(TPHIP_SITE_PERSISTENT="0", TPHIP_SITE_CHUNK="1000")]
+    ref = None
+    for env in settings:
+        for k in ("TPHIP_SITE_PERSISTENT", "TPHIP_SITE_WAVES", "TPHIP_SITE_GRID_MULT", "TPHIP_SITE_FIRST_FRACTION", "TPHIP_SITE_CHUNK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = engine.Plan(24, pin["parent"], pin["blen"], pin["leaf"], off, d["pi"], d["exch"], pin["T"], [10], [[5, 15]],
+                           correction=pin["correction"])
+        got = plan.site_rates(st)
+        plan.close()
+        if ref is None:
+            ref = got
+            assert (got["flag"] == 0).sum() > 5000
+        else:
+            for key in ("rate", "subst", "lnl", "flag", "nres"):
+                assert np.array_equal(got[key], ref[key], equal_nan=(got[key].dtype.kind == "f")), (env, key)
+
+
 def test_hyphy_protocol_shim(golden_dir, tmp_path, oracle):
     """Boundary #1: `--hyphy /path/to/tphip_hyphy` -- argv = [exe, template], three stdin lines, JSON
     file out, stdout must not start with "Error"; the file must parse the way tapir/compute.py:24-44 parses it."""
