@@ -4,16 +4,23 @@
 A "step" is one pass of the hot path (classify -> compact -> per-site rate ML -> PI tables, plus the
 all-gather of PI tables when N > 1) over one batch of synthetic loci already resident in HBM.
 
-  python bench.py                       one GPU, workload C3 (100 loci x 50 000 columns x 64 taxa)
+  python bench.py                       one GPU, workload C3 (100 loci x 50 000 columns x 64 taxa): the headline
+  python bench.py --workload C4         one GPU, the WHOLE 8-GPU config C4 (50 000 loci x 1 000 x 64; 3.2 GB: it fits)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-         bench.py --gpus N --steps K --warmup W        weak scaling: every rank owns one C3-sized shard
+         bench.py --gpus N --steps K --warmup W
+      N > 1: STRONG scaling of one fixed config (default C4): every rank generates the same seeded batch, keeps the
+      loci i with i mod N == rank (what Pool.map(worker, params) did over cores, bin/tapir_compute.py:159-164), runs
+      its share, and one all-gather (RCCL) collects the [L, W] PI table; after the timed region rank 0 runs the whole
+      config alone and requires the gathered table to be bit-identical to its own.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) with the extra objects `roofline` (dominant
 kernel = site_rate_kernel; algorithmic bytes = (ntaxa + 24) per column), `fp64` (the bound
 that actually binds this path) and `cpu_baseline` (the CPU oracle timed on the box's host cores on a
-bounded sample of the same workload; a reported baseline, not the target).
+bounded sample of the same workload, one core and all usable cores; a reported baseline, not the target),
+whose `parity_sample` is the GPU-vs-oracle gate SURVEY 8d attaches to every measurement: the run fails on a mismatch.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -42,29 +49,78 @@ def flops_per_eval(oc):
             - oc.get("cherry", 0) * 57)
 
 
+def usable_cpus():
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+# ---- CPU oracle legs (bench.py's cpu_baseline is one of the three places allowed to call oracle/) ----------------
+
+def _oracle_job(job):
+    """One locus sample through the oracle: site-rate ML + rounding / correction / cull + net PI + dqagse integrals,
+    i.e. the same stages the GPU step runs.  Returns (seconds, rate, flag, nres, net, integrals, errors)."""
+    st, parent, blen, leaf, pi, exch, correction, T, intervals = job
+    from oracle import oracle as orc
+    orc.lib()
+    t0 = time.perf_counter()
+    r = orc.site_rates(st, parent, blen, leaf, pi, exch)
+    rates = orc.round_dp(r["rate"], 4) / correction
+    rates[r["nres"] < 3] = np.nan
+    net = orc.net_pi(rates, T)
+    si, se = orc.net_integrals(rates, intervals, 0)
+    return time.perf_counter() - t0, r["rate"], r["flag"], r["nres"], net, si, se
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
-    ap.add_argument("--loci", type=int, default=None, help="override loci per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration (0 = skip)")
+    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5"],
+                    help="default: C3 on one GPU (the headline), C4 dealt over the ranks when --gpus > 1")
+    ap.add_argument("--loci", type=int, default=None, help="override the number of loci of the config (experiments)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration per leg (0 = skip)")
     ap.add_argument("--stage1-loci", type=int, default=4,
                     help="also time HyPhy's stage 1 (model-averaged exchangeabilities) on the first N loci (0 = skip)")
     ap.add_argument("--gamma-categories", type=int, default=1,
                     help="K > 1: opt-in discrete-gamma rate mixture in the site-rate stage (alpha 0.5); not the headline config")
     ap.add_argument("--integ-mode", type=int, default=0, help="0 = QUADPACK emulation (reference parity), 1 = closed form")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with a gloo process group (tables staged through the host for the "
+                         "collective): rehearses the sharded code path on a one-GPU box; not a measurement")
+    ap.add_argument("--no-single-gpu-check", action="store_true",
+                    help="N > 1: skip rank 0's run of the whole config (the bit-identity check of the gathered table)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    workload = args.workload or ("C3" if world == 1 else "C4")
+
+    # The all-cores CPU leg needs worker processes; they are forked HERE, before torch is imported and before anything
+    # touches the GPU (a fork of a process that holds a HIP context inherits its KFD state), and sit idle until the
+    # GPU part is over.
+    cpu_pool, cpu_workers = None, 0
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        import multiprocessing
+        from oracle import oracle as orc
+        orc.build()
+        cpu_workers = max(1, min(usable_cpus() - 1, 64))
+        cpu_pool = multiprocessing.get_context("fork").Pool(cpu_workers)
 
     import torch
     from tapir_amd import dist as tdist
     from tapir_amd import engine, synth
 
-    rank, world = tdist.rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if engine.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -77,43 +133,66 @@ def main():
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            if args.rehearse_on_one_gpu:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
-    nloci_full, ncols, ntaxa, times, intervals = synth.WORKLOADS[args.workload]
-    # per-GPU share: C2/C3 are single-GPU configs (whole config per GPU); C4/C5 are 8-GPU configs (1/8 per GPU)
-    share = {"C2": nloci_full, "C3": nloci_full, "C4": nloci_full // 8, "C5": nloci_full // 8}[args.workload]
-    nloci = args.loci or share
-    seed = synth.WORKLOAD_SEED[args.workload]
+    nloci_full, ncols, ntaxa, times, intervals = synth.WORKLOADS[workload]
+    nloci_full = args.loci or nloci_full
+    seed = synth.WORKLOAD_SEED[workload]
 
+    # every rank generates the SAME batch (rank-independent seed) and keeps its round-robin share of the loci
     t_gen = time.time()
     tree = synth.yule_tree(ntaxa, seed)
-    data = synth.simulate(nloci, ncols, ntaxa, seed + 1000 * rank, device=dev, tree=tree)
+    data = synth.simulate(nloci_full, ncols, ntaxa, seed, device=dev, tree=tree)
     pin = synth.plan_inputs(data["root"], data["names"])
+    mine = tdist.shard_loci(nloci_full, rank, world)
+    nloci = len(mine)
+    if world > 1:
+        idx = torch.from_numpy(mine).to(dev)
+        d_states = data["states"].view(ntaxa, nloci_full, ncols)[:, idx, :].reshape(ntaxa, nloci * ncols).contiguous()
+        if rank != 0 or args.no_single_gpu_check:
+            data["states"] = None   # only rank 0 needs the whole batch again (single-GPU check)
+    else:
+        d_states = data["states"]
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
-    plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], data["locus_offsets"], data["pi"], data["exch"],
-                       pin["T"], times, intervals, correction=pin["correction"], threshold=3, round_decimals=4,
-                       integ_mode=args.integ_mode, device=local_rank,
-                       **({} if args.gamma_categories <= 1 else
-                          dict(zip(("cat_rates", "cat_weights"), __import__("tapir_amd.compute", fromlist=["x"]).discrete_gamma(0.5, args.gamma_categories)))))
+    def make_plan(loci_idx):
+        off = np.arange(len(loci_idx) + 1, dtype=np.int64) * ncols
+        extra = {}
+        if args.gamma_categories > 1:
+            from tapir_amd import compute
+            extra = dict(zip(("cat_rates", "cat_weights"), compute.discrete_gamma(0.5, args.gamma_categories)))
+        return engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, data["pi"][loci_idx], data["exch"][loci_idx],
+                           pin["T"], times, intervals, correction=pin["correction"], threshold=3, round_decimals=4,
+                           integ_mode=args.integ_mode, device=local_rank, **extra)
+
+    def buffers(plan, nl):
+        n = plan.ncols
+        return dict(rate=torch.empty(n, dtype=torch.float64, device=dev), subst=torch.empty(n, dtype=torch.float64, device=dev),
+                    lnl=torch.empty(n, dtype=torch.float64, device=dev), flag=torch.empty(n, dtype=torch.uint8, device=dev),
+                    nres=torch.empty(n, dtype=torch.int32, device=dev),
+                    tables=torch.empty((nl, plan.width), dtype=torch.float64, device=dev),
+                    ws=torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev))
+
+    plan = make_plan(mine)
     n = plan.ncols
-    W = plan.width
-    d_states = data["states"]
-    d_rate = torch.empty(n, dtype=torch.float64, device=dev)
-    d_subst = torch.empty(n, dtype=torch.float64, device=dev)
-    d_lnl = torch.empty(n, dtype=torch.float64, device=dev)
-    d_flag = torch.empty(n, dtype=torch.uint8, device=dev)
-    d_nres = torch.empty(n, dtype=torch.int32, device=dev)
-    d_tables = torch.empty((nloci, W), dtype=torch.float64, device=dev)
-    d_ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * nloci, W), dtype=torch.float64, device=dev) if use_dist else None
+    B = buffers(plan, nloci)
+    gather_buf = {}
+    result = {}
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
-        plan.run_dev(d_states, d_rate, d_subst, d_lnl, d_flag, d_nres, d_tables, d_ws, stream)
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, d_tables)  # the one collective: [L/G, W] PI tables per rank
+        plan.run_dev(d_states, B["rate"], B["subst"], B["lnl"], B["flag"], B["nres"], B["tables"], B["ws"], stream)
+        if use_dist:   # the one collective: [ceil(L/G), W] PI rows per rank -> the [L, W] table in locus order
+            if args.rehearse_on_one_gpu:
+                result["table"] = tdist.gather_tables(B["tables"].cpu(), nloci_full, rank, world, always=True).to(dev)
+            else:
+                result["table"] = tdist.gather_tables(B["tables"], nloci_full, rank, world, buffers=gather_buf, always=True)
+        else:
+            result["table"] = B["tables"]
 
     def sync():
         if use_dist:
@@ -133,18 +212,34 @@ def main():
     site_ms, pi_ms, launches = plan.profile_read(reset=True)
     plan.profile_enable(False)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     evals = plan.last_eval_count()
 
-    total_cols = n * world
+    total_cols = nloci_full * ncols
     value = total_cols * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     site_avg_ms = site_ms / max(1, launches)
     pi_avg_ms = pi_ms / max(1, launches)
     alg_bytes = n * (ntaxa + 24)  # per launch of the dominant kernel, this rank
     achieved = alg_bytes / (site_avg_ms * 1e-3) / 1e9 if site_avg_ms > 0 else 0.0
+
+    table = result["table"]
+    table_sha = hashlib.sha256(table.cpu().numpy().tobytes()).hexdigest() if rank == 0 else None
+    single_check = None
+    if world > 1 and rank == 0 and not args.no_single_gpu_check:
+        # the whole config on this one GPU: the gathered table of the sharded run must carry the same bits
+        full_plan = make_plan(np.arange(nloci_full))
+        FB = buffers(full_plan, nloci_full)
+        full_plan.run_dev(data["states"], FB["rate"], FB["subst"], FB["lnl"], FB["flag"], FB["nres"], FB["tables"], FB["ws"],
+                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        single_check = bool(torch.equal(FB["tables"], table))
+        full_plan.close()
+        del FB
+        if not single_check:
+            raise SystemExit("PARITY FAILURE: the table gathered from %d ranks differs from the single-GPU table" % world)
 
     # what the HBM roof is on this very device: a device-to-device copy of 1 GiB (read + write counted)
     hbm_copy_gbs = None
@@ -164,11 +259,11 @@ def main():
     # (profiles/: separate --pmc passes, FETCH_SIZE calibrated on classify_kernel's known byte count)
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and world == 1:
         with open(pmc_path) as fh:
-            traffic = json.load(fh).get(args.workload, {}).get("site_rate_kernel_bytes")
+            traffic = json.load(fh).get(workload, {}).get("site_rate_kernel_bytes")
 
-    flags = torch.bincount(d_flag.to(torch.int64), minlength=5).cpu().numpy().tolist()
+    flags = torch.bincount(B["flag"].to(torch.int64), minlength=5).cpu().numpy().tolist()
     fl_eval = flops_per_eval(plan.op_counts)
     fp64_tflops = evals * fl_eval / (site_avg_ms * 1e-3) / 1e12 if site_avg_ms > 0 else 0.0
 
@@ -181,18 +276,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (seeded Yule tree, GTR-simulated columns, Gamma(0.5) site rates, 5% gaps; SURVEY.md 8d)",
         "config": {
-            "workload": "%s shape per GPU: %d loci x %d columns x %d taxa, per-site GTR rate ML + PI "
+            "workload": "%s: %d loci x %d columns x %d taxa, per-site GTR rate ML + PI "
                         "(T=%d net times, %d --times, %d --intervals, integ_mode=%d)%s"
-                        % (args.workload, nloci, ncols, ntaxa, pin["T"], len(times), len(intervals), args.integ_mode,
+                        % (workload, nloci_full, ncols, ntaxa, pin["T"], len(times), len(intervals), args.integ_mode,
                            "" if args.gamma_categories <= 1 else ", +G mixture of %d rate categories (extension)" % args.gamma_categories),
+            "total_columns": total_cols,
             "columns_per_gpu": n,
             "loci_per_gpu": nloci,
-            "parallelism": "loci sharded over %d rank(s), one all-gather of PI tables" % world,
+            "parallelism": ("whole config on one GPU" if world == 1 else
+                            "one fixed config, locus i -> rank i mod %d, one all-gather of PI tables" % world),
             "stack_depth": plan.stack_depth,
         },
         "roofline": {
@@ -201,7 +298,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_avg_ms": site_avg_ms,
             "hbm_copy_measured_gbs": hbm_copy_gbs,
             "note": "BASELINE.json mandates the HBM figure; the path is FP64-VALU bound (see fp64); traffic = PMC "
-                    "FETCH_SIZE (calibrated) + WRITE_SIZE bytes per launch from profiles/pmc_traffic.json",
+                    "FETCH_SIZE (calibrated) + WRITE_SIZE bytes per launch from profiles/pmc_traffic.json; rank 0's share",
         },
         "fp64": {
             "evals_per_launch": evals, "evals_per_column": evals / max(1, n), "flop_per_eval_model": fl_eval,
@@ -210,29 +307,39 @@ def main():
         },
         "stages_ms": {"site_rate_kernel": site_avg_ms, "pi_kernels": pi_avg_ms, "step_total": ms_per_step},
         "flags": dict(zip(["ok", "flat", "saturated", "zero", "maxit"], flags)),
+        "table_sha256": table_sha,
+        "gathered_equals_single_gpu": single_check,
         "gen_seconds": t_gen,
     }
+    if args.rehearse_on_one_gpu:
+        out["rehearsal"] = "all %d ranks on cuda:0, gloo collective through the host: NOT a measurement" % world
 
+    parity_failure = None
     if rank == 0 and world == 1 and args.stage1_loci > 0:
         out["stage1"] = stage1_sample(data, pin, min(args.stage1_loci, nloci), ncols, ntaxa, times, intervals)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(plan, data, pin, nloci, ncols, ntaxa, times, intervals, args, d_rate, d_nres)
+        out["cpu_baseline"], parity_failure = cpu_baseline(cpu_pool, cpu_workers, data, pin, nloci, ncols, ntaxa, times,
+                                                           intervals, args, B, plan)
+    if cpu_pool is not None:
+        cpu_pool.close()
+        cpu_pool.join()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if use_dist:
-        # every rank's rows are in `gathered`; rank r's block must be bit-identical to its own table
-        assert torch.equal(gathered[rank * nloci:(rank + 1) * nloci], d_tables)
+        # every rank's own rows must sit, bit-identical, at their round-robin places of the gathered table
+        assert torch.equal(table[torch.from_numpy(mine).to(dev)], B["tables"])
     plan.close()
     if use_dist:
         dist.destroy_process_group()
+    if parity_failure:
+        raise SystemExit("PARITY FAILURE (GPU vs CPU oracle on the bench's own columns): " + parity_failure)
 
 
 def stage1_sample(data, pin, nl, ncols, ntaxa, times, intervals):
     """Not part of `value`: wall time of the stage that precedes the per-site loop in HyPhy's script (203-model fit +
     Akaike averaging of the exchangeabilities, models_and_rates.bf:405-897) on the first loci of the same batch, through
     the product path (pattern compression, likelihood + gradient kernels, tapir_amd/stage1.py)."""
-    import time
-    import numpy as np
     from tapir_amd import engine, nexus, pipeline
     st = data["states"][:, :nl * ncols].cpu().numpy()
     off = np.arange(nl + 1, dtype=np.int64) * ncols
@@ -248,37 +355,82 @@ def stage1_sample(data, pin, nl, ncols, ntaxa, times, intervals):
             "max_rel_dev_from_generating_rates": float(np.max(np.abs(exch - true / true[:, 1:2]) / (true / true[:, 1:2])))}
 
 
-def cpu_baseline(plan, data, pin, nloci, ncols, ntaxa, times, intervals, args, d_rate, d_nres):
-    """The CPU oracle (oracle/tapir_oracle.c, single thread) on a bounded sample of the same bytes:
-    site-rate ML + net PI + QUADPACK interval integrals, i.e. the same stages the GPU step runs."""
-    from oracle import oracle as orc
-    orc.lib()
+def cpu_baseline(pool, workers, data, pin, nloci, ncols, ntaxa, times, intervals, args, B, plan):
+    """The CPU oracle (oracle/tapir_oracle.c) on bounded samples of the same bytes, two legs:
+      single thread -- the analogue of single-threaded hyphy2, one locus at a time;
+      all cores     -- one oracle worker per locus over the pool forked at start-up, the analogue of
+                       Pool(cpu_count() - 1).map(worker, params) (bin/tapir_compute.py:162-163).
+    Every column the oracle processes is also compared with what the GPU just produced for it (parity_sample)."""
     st = data["states"]
+    T = pin["T"]
+    d_rate, d_flag, d_nres, d_tables = B["rate"], B["flag"], B["nres"], B["tables"]
+    par = dict(columns=0, loci_with_tables=0, max_rel_rate=0.0, flag_mismatches=0, nres_mismatches=0, tables_max_rel=0.0)
 
-    def run(l0, c0, c1):
-        sl = st[:, l0 * ncols + c0:l0 * ncols + c1].cpu().numpy()
-        t0 = time.perf_counter()
-        r = orc.site_rates(sl, pin["parent"], pin["blen"], pin["leaf"], data["pi"][l0], data["exch"][l0])
-        rates = orc.round_dp(r["rate"], 4) / pin["correction"]
-        rates[r["nres"] < 3] = np.nan
-        orc.net_pi(rates, pin["T"])
-        orc.net_integrals(rates, intervals, 0)
-        return time.perf_counter() - t0
+    def job(l, c1):
+        sl = st[:, l * ncols:l * ncols + c1].cpu().numpy()
+        return (sl, pin["parent"], pin["blen"], pin["leaf"], data["pi"][l], data["exch"][l], pin["correction"], T, intervals)
 
+    def check(l, c1, res):
+        _, rate, flag, nres, net, si, se = res
+        g_rate = d_rate[l * ncols:l * ncols + c1].cpu().numpy()
+        g_flag = d_flag[l * ncols:l * ncols + c1].cpu().numpy()
+        g_nres = d_nres[l * ncols:l * ncols + c1].cpu().numpy()
+        par["columns"] += c1
+        par["flag_mismatches"] += int((g_flag != flag).sum())
+        par["nres_mismatches"] += int((g_nres != nres).sum())
+        ok = ((flag == 0) | (flag == 3)) & (g_flag == flag)
+        if ok.any():
+            rel = np.abs(g_rate[ok] - rate[ok]) / np.maximum(np.abs(rate[ok]), 1e-12)
+            par["max_rel_rate"] = max(par["max_rel_rate"], float(rel.max()))
+        if c1 == ncols and args.gamma_categories <= 1:   # a whole locus: its PI row is comparable too
+            row = d_tables[l].cpu().numpy()
+            n_t, n_i = len(times), len(intervals)
+            ref = np.concatenate([net, net[np.asarray(times, dtype=np.int64)], si])
+            got = row[:T + n_t + n_i]
+            par["tables_max_rel"] = max(par["tables_max_rel"], float(np.max(np.abs(got - ref)) / max(1e-300, np.abs(ref).max())))
+            par["loci_with_tables"] += 1
+
+    # ---- leg 1: one thread
     probe_cols = min(ncols, 512)
-    t_probe = run(0, 0, probe_cols)
-    per_col = t_probe / probe_cols
+    res = _oracle_job(job(0, probe_cols))
+    per_col = res[0] / probe_cols
     want = int(max(probe_cols, min(nloci * ncols, args.cpu_seconds / per_col)))
     done, t_total, l = 0, 0.0, 0
     while done < want and l < nloci:
         c1 = min(ncols, want - done)
-        t_total += run(l, 0, c1)
+        res = _oracle_job(job(l, c1))
+        check(l, c1, res)
+        t_total += res[0]
         done += c1
         l += 1
-    return {"value": done / t_total, "unit": "columns/s", "cores": 1, "kind": "port",
-            "sample": "first %d columns of the same synthetic batch (%d loci), oracle/tapir_oracle.c single thread, "
-                      "site-rate ML + net PI + dqagse integrals, %.1f s" % (done, l, t_total),
-            "host_cpus": os.cpu_count()}
+    single = done / t_total
+    out = {"value": single, "unit": "columns/s", "cores": 1, "kind": "port",
+           "sample": "first %d columns of the same synthetic batch (%d loci), oracle/tapir_oracle.c single thread, "
+                     "site-rate ML + net PI + dqagse integrals, %.1f s" % (done, l, t_total),
+           "host_cpus": os.cpu_count(), "usable_cpus": usable_cpus()}
+    # ---- leg 2: all usable cores, one locus sample per task (different loci than leg 1 where the batch has them)
+    if pool is not None and workers >= 1:
+        per_task = int(max(64, min(ncols, args.cpu_seconds * single / 2)))   # ~cpu_seconds / 2 of work per task, 2 rounds
+        first = l if l + 2 * workers <= nloci else 0
+        loci = [(first + k) % nloci for k in range(min(2 * workers, nloci))]
+        jobs = [job(x, per_task) for x in loci]
+        t0 = time.perf_counter()
+        results = pool.map(_oracle_job, jobs, chunksize=1)
+        wall = time.perf_counter() - t0
+        for x, r in zip(loci, results):
+            check(x, per_task, r)
+        out["all_cores"] = {"value": len(jobs) * per_task / wall, "unit": "columns/s", "cores": workers,
+                            "sample": "%d tasks of %d columns (one locus each) over %d forked oracle workers, %.1f s wall, "
+                                      "%.1f s of CPU work" % (len(jobs), per_task, workers, wall, sum(r[0] for r in results))}
+    out["parity_sample"] = par
+    failure = None
+    if par["flag_mismatches"] or par["nres_mismatches"]:
+        failure = "%d flag and %d informative-count mismatches" % (par["flag_mismatches"], par["nres_mismatches"])
+    elif par["max_rel_rate"] > 1e-6:
+        failure = "site rates differ by %.3g relative (tolerance 1e-6)" % par["max_rel_rate"]
+    elif par["tables_max_rel"] > 1e-9:
+        failure = "PI table rows differ by %.3g relative (tolerance 1e-9)" % par["tables_max_rel"]
+    return out, failure
 
 
 if __name__ == "__main__":

@@ -150,6 +150,14 @@ int tphip_run_dev(tphip_plan *plan, const uint8_t *d_states, double *d_rate, dou
                   uint8_t *d_flag, int32_t *d_nres, double *d_tables, void *d_workspace,
                   size_t workspace_bytes, void *stream);
 
+/* parse_site_rates + cull_uninformative_rates as the PI stage applies them to a raw rate (tapir/compute.py:24-44,
+ * 108-110; bin/tapir_compute.py:100-102): d_out[c] = R4(d_rates[c]) / correction, NaN where d_nres[c] < threshold
+ * (d_nres may be NULL: no cull -- what parse_site_rates alone returns and writes as `corrected_rates`).  R4 is the
+ * round trip through HyPhy's Format(x,0,4) (bf:1093-1095): the double nearest to the decimal that printf-style
+ * rounding of the exact binary value gives (skipped when round_decimals < 0). */
+int tphip_corrected_rates_dev(tphip_plan *plan, const double *d_rates, const int32_t *d_nres, double *d_out,
+                              void *stream);
+
 /* tapir/compute.py:46-48 get_townsend_pi(time, rates) as a dense (n_times, n) matrix, row-major:
  * out[k*n + i] = 16 r_i^2 t_k exp(-4 r_i t_k).  NaN rates propagate (numpy semantics). */
 int tphip_townsend_pi_dense_dev(int32_t device, const double *d_rates, int64_t n, const double *d_times,
@@ -208,6 +216,7 @@ int tphip_last_eval_count(tphip_plan *plan, int64_t *evals);
 int tphip_site_rates(tphip_plan *plan, const uint8_t *states, double *rate, double *subst, double *lnl,
                      uint8_t *flag, int32_t *nres);
 int tphip_pi_tables(tphip_plan *plan, const double *rates, const int32_t *nres, double *tables);
+int tphip_corrected_rates(tphip_plan *plan, const double *rates, const int32_t *nres, double *out);
 int tphip_run_fused(tphip_plan *plan, const uint8_t *states, double *rate, double *subst, double *lnl,
                     uint8_t *flag, int32_t *nres, double *tables);
 int tphip_townsend_pi_dense(int32_t device, const double *rates, int64_t n, const double *times, int32_t n_times,
@@ -248,6 +257,9 @@ int tphip_plan_set_column_weights(tphip_plan *plan, const double *weights);
 /* Diagnostic (tests): log L and its first two derivatives with respect to u = log(siteRate) for every
  * column at a caller-chosen u[ncols]; no classification, no optimiser.  Host pointers. */
 int tphip_eval_columns(tphip_plan *plan, const uint8_t *states, const double *u, double *f, double *g, double *h);
+/* device-pointer twin (full-size property tests: nothing crosses PCIe); enqueues on `stream`, does not synchronise */
+int tphip_eval_columns_dev(tphip_plan *plan, const uint8_t *d_states, const double *d_u, double *d_f, double *d_g,
+                           double *d_h, void *stream);
 
 #ifdef __cplusplus
 }

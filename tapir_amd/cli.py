@@ -151,6 +151,20 @@ def main(argv=None, engine_mod=None):
     args = get_args(argv)
     rank, world = tdist.rank_world()
     on_gpu = engine_mod is None
+    pool = None
+    if args.multiprocessing:  # the reference: Pool(processes = cpu_count() - 1), bin/tapir_compute.py:162-163
+        from multiprocessing import cpu_count
+        # forked here, before torch.distributed / RCCL and before the first libtphip call: see pipeline.HostPool
+        # (forking hundreds of workers costs more than it saves: at most 16 per rank)
+        pool = pipeline.HostPool(max(1, min(16, (cpu_count() - 1) // world)))
+    try:
+        return _main(args, rank, world, on_gpu, engine_mod, pool)
+    finally:
+        if pool is not None:
+            pool.close()
+
+
+def _main(args, rank, world, on_gpu, engine_mod, pool):
     if world > 1:
         tdist.init_process_group(None if on_gpu else "gloo")
         if on_gpu:
@@ -172,10 +186,6 @@ def main(argv=None, engine_mod=None):
     leaf_names = [n.name for n in newick.leaves(root)]
     parent, blen, leaf = newick.to_arrays(root, leaf_names)
     integ_mode = 0 if args.integral_mode == 'quadpack' else 1
-    workers = 1
-    if args.multiprocessing:  # the reference: Pool(processes = cpu_count() - 1), bin/tapir_compute.py:162-163
-        from multiprocessing import cpu_count
-        workers = max(1, min(16, (cpu_count() - 1) // world))  # forking hundreds of workers costs more than it saves
     progress = pipeline.dot_progress if rank == 0 else None
     cat_rates, cat_weights = (compute.discrete_gamma(args.gamma_alpha, args.gamma_categories)
                               if args.gamma_categories > 1 else (None, None))
@@ -195,7 +205,7 @@ def main(argv=None, engine_mod=None):
                                                correction, args.threshold, exch, pi=pi, subsets=subset_pi,
                                                output_dir=args.output, device=args.device, integ_mode=integ_mode,
                                                round_decimals=-1 if args.full_precision_rates else 4,
-                                               engine_mod=engine_mod, progress=progress, workers=workers,
+                                               engine_mod=engine_mod, progress=progress, pool=pool,
                                                cat_rates=cat_rates, cat_weights=cat_weights)
             tables = out["final_tables"]
         else:

@@ -31,6 +31,27 @@ def parse_site_rates(rate_file, correction=1, test=False, count=0):
     return corrected
 
 
+def round_like_hyphy(x, decimals=4):
+    """The value tapir reads back from a number HyPhy wrote with Format(x, 0, decimals) (models_and_rates.bf:1093-1095):
+    the double nearest to the decimal that printf-style rounding of the EXACT binary value gives (= float("%.4f" % x)),
+    vectorised.  numpy.round(x * 1e4) / 1e4 is not that: the product is rounded, so it can sit exactly on a
+    half-integer the true product only comes close to, and the answer is then off by 1e-4.  Only those elements (a
+    half-integer product) are ambiguous; they are settled by the exact decimal conversion itself.  Same rule as
+    round_like_printf in csrc/pi_kernels.hpp."""
+    x = np.asarray(x, dtype=np.float64)
+    scale = 10.0 ** decimals
+    p = x * scale
+    n = np.rint(p)
+    out = n / scale
+    tie = np.flatnonzero(np.abs(p - n).reshape(-1) == 0.5)
+    if tie.size:
+        flat = out.reshape(-1)   # a view: out is a fresh contiguous array
+        src = x.reshape(-1)
+        for i in tie:
+            flat[i] = float("%.*f" % (decimals, src[i]))
+    return out
+
+
 def get_townsend_pi(time, rates, device=0):
     """Townsend et al. equation 10 as coded: 16 * rates**2 * time * exp(-4 * rates * time), on the GPU.
 

@@ -307,9 +307,23 @@ struct PiParams {
 
 // rate as tapir sees it after the JSON round trip, the /correction and the cull
 // (bf:1093-1095 Format(x,0,4); tapir/compute.py:38-39; tapir/compute.py:96-110)
+// HyPhy writes Format(x,0,4) (bf:1093-1095) and tapir parses the text back: the double nearest to the decimal that
+// printf-style rounding of the EXACT binary value gives (ties to even).  rint(r * 10^4) / 10^4 is not that: the product
+// is itself rounded, so it can land exactly on a half-integer the true product only comes close to (a false tie, decided
+// by parity instead of by the discarded part) -- the rate would then differ by 1e-4 from what the .rates file says.
+// The FMA recovers the discarded part exactly (r * scale = p + e), and only a half-integer p needs it: otherwise p is
+// at least one ulp away from the half and |e| <= ulp/2 cannot carry it across.
+__host__ __device__ __forceinline__ double round_like_printf(double r, double scale) {
+    const double p = r * scale;
+    const double e = fma(r, scale, -p);
+    double n = rint(p);
+    if (fabs(p - n) == 0.5 && e != 0.0) n = (e > 0.0) ? p + 0.5 : p - 0.5;
+    return n / scale;   // correctly rounded quotient of two exact doubles = strtod of the decimal string
+}
+
 __device__ __forceinline__ double finalize_rate(const PiParams& P, int64_t col) {
     double r = P.rates[col];
-    if (P.round_scale > 0.0) r = rint(r * P.round_scale) / P.round_scale;
+    if (P.round_scale > 0.0) r = round_like_printf(r, P.round_scale);
     r = r / P.correction;
     if (P.nres && P.nres[col] < P.threshold) r = __longlong_as_double(0x7ff8000000000000ll);
     return r;
@@ -454,6 +468,13 @@ __global__ void pi_reduce_kernel(const double* __restrict__ partial, const int64
         const int dst = (w < T) ? w : (w < Wp ? w + n_t : T + (w - Wp));
         row[dst] = s;
     }
+}
+
+// parse_site_rates + cull_uninformative_rates as the PI kernels see a rate (tapir/compute.py:38-39, 108-110):
+// out[c] = round4(rate[c]) / correction, NaN where nres[c] < threshold (nres may be null: no cull).
+__global__ void corrected_rates_kernel(PiParams P, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = finalize_rate(P, i);
 }
 
 // tapir/compute.py:46-48 as a dense (n_times, n) matrix: out[k*n + i] = 16 r_i^2 t_k exp(-4 r_i t_k).

@@ -38,6 +38,7 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 constexpr int kProfileRing = 1024;
+constexpr double kPiFloor = 1e-12;
 
 template <typename T>
 struct DevBuf {
@@ -120,6 +121,7 @@ struct tphip_plan {
     int32_t site_persistent = 1;
     int32_t site_grid_mult = 1;   // persistent grid = resident waves x this (see plan creation)
     double site_first_fraction = 0.0;   // share of the work the first round of shares takes (0 = equal shares)
+    bool force_byte_path = false;       // TPHIP_FORCE_BYTE_PATH=1 at plan creation: run the NW = 0 kernel on any tree (tests)
     // profiling
     bool profile = false;
     std::vector<hipEvent_t> ev;  // 4 events per slot: site start/stop, pi start/stop
@@ -183,8 +185,13 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     if (d->locus_offsets[0] != 0) return fail(TPHIP_ERR_INVALID, "locus_offsets[0] must be 0");
     for (int64_t l = 0; l < d->nloci; ++l) {
         if (d->locus_offsets[l + 1] < d->locus_offsets[l]) return fail(TPHIP_ERR_INVALID, "locus_offsets not monotone");
-        for (int k = 0; k < 4; ++k)
-            if (!(d->pi[l * 4 + k] > 0.0)) return fail(TPHIP_ERR_INVALID, "base frequencies must be > 0");
+        int npos = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (!(d->pi[l * 4 + k] >= 0.0) || !std::isfinite(d->pi[l * 4 + k]))
+                return fail(TPHIP_ERR_INVALID, "base frequencies of locus " + std::to_string(l) + " must be finite and >= 0");
+            npos += d->pi[l * 4 + k] > 0.0;
+        }
+        if (npos < 2) return fail(TPHIP_ERR_INVALID, "locus " + std::to_string(l) + " has fewer than two bases with a positive frequency");
         for (int k = 0; k < 6; ++k)
             if (!(d->exch[l * 6 + k] >= 0.0)) return fail(TPHIP_ERR_INVALID, "exchangeabilities must be >= 0");
     }
@@ -249,6 +256,16 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     std::vector<int32_t> times(d->times, d->times + d->n_t), iv(d->intervals, d->intervals + 2 * (size_t)d->n_i);
     DevBuf<double> d_pi, d_exch;
     std::vector<double> hpi(d->pi, d->pi + 4 * (size_t)d->nloci), hex(d->exch, d->exch + 6 * (size_t)d->nloci);
+    // A base that never occurs in a (short) locus has empirical frequency 0 (HarvestFrequencies, bf:968); HyPhy takes
+    // that as it is: the state is unreachable and no tip carries it, so the likelihood is that of the three-state
+    // model.  The eigen-form used here needs D^-1/2, so the zero is floored at kPiFloor before the renormalisation in
+    // gtr_setup_kernel: the dead state then enters every likelihood with weight O(1e-12), below the 1e-9 the parity
+    // tests resolve.
+    for (int64_t l = 0; l < d->nloci; ++l) {
+        double sum = 0;
+        for (int k = 0; k < 4; ++k) sum += hpi[4 * l + k];
+        for (int k = 0; k < 4; ++k) hpi[4 * l + k] = std::max(hpi[4 * l + k], kPiFloor * sum);
+    }
     std::vector<int32_t> tip_taxon;
     for (const TreeOp& op : p->prog.ops) if (op.code <= OP_TIP_MUL) tip_taxon.push_back(op.taxon);
     p->nwords = (int32_t)((tip_taxon.size() + 7) / 8);
@@ -337,6 +354,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
             p->grad_blocks_per_cu = bpc;
         }
         if (const char* env = getenv("TPHIP_LIK_NSPLIT")) p->lik_nsplit_forced = std::max(1, atoi(env));
+        if (const char* fb = getenv("TPHIP_FORCE_BYTE_PATH")) p->force_byte_path = (fb[0] == '1');
         // Small batches (an equal share would be under ~1000 columns) run one workgroup per locus-aligned
         // slice instead: cutting a small locus in two doubles its prologue and drain (measured on C2).
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
@@ -457,6 +475,8 @@ int tphip_last_eval_count(tphip_plan* p, int64_t* evals) {
 
 // ---- launches ------------------------------------------------------------------------------------
 
+static PiParams pi_params(const tphip_plan* p, const double* d_rates, const int32_t* d_nres, void* ws);
+
 static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_rate, double* d_subst, double* d_lnl,
                              uint8_t* d_flag, int32_t* d_nres, void* ws, hipStream_t st, int slot) {
     int32_t* work_cols = (int32_t*)((char*)ws + p->ws_work_cols);
@@ -497,8 +517,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     if (p->n_site_chunks > 0) {
         const dim3 grid((unsigned)(p->site_persistent ? p->site_waves * p->site_grid_mult : p->n_site_chunks)), block(kSiteBlock);
         // packed tip states: in registers up to 64 tips, streamed one word ahead beyond (site_rate_kernel.hpp)
-        const char* fb = getenv("TPHIP_FORCE_BYTE_PATH");  // test/tuning knob: exercise the NW = 0 kernel on any tree
-        const bool byte_path = (fb && fb[0] == '1');
+        const bool byte_path = p->force_byte_path;   // test/tuning knob, resolved at plan creation
         if (!byte_path) {  // the packed path reads the stream with fused cherries (tree_program.hpp)
             S.ops = p->d_fused_ops.p;
             S.nops = (int32_t)p->prog.fused_ops.size();
@@ -515,13 +534,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
 
 static int launch_pi_tables(tphip_plan* p, const double* d_rates, const int32_t* d_nres, double* d_tables, void* ws,
                             hipStream_t st, int slot) {
-    PiParams Q;
-    Q.rates = d_rates; Q.nres = d_nres; Q.locus_offsets = p->d_offsets.p;
-    Q.chunk_locus = p->d_pi_chunk_locus.p; Q.chunk_index = p->d_pi_chunk_index.p;
-    Q.T = p->T; Q.intervals = p->d_intervals.p; Q.n_i = p->n_i; Q.integ_mode = p->integ_mode;
-    Q.correction = p->correction; Q.threshold = p->threshold;
-    Q.round_scale = (p->round_decimals >= 0) ? std::pow(10.0, (double)p->round_decimals) : 0.0;
-    Q.partial = (double*)((char*)ws + p->ws_partial);
+    PiParams Q = pi_params(p, d_rates, d_nres, ws);
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 2], st));
     if (p->n_pi_chunks > 0) pi_partial_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(Q);
     pi_reduce_kernel<<<dim3((unsigned)p->nloci), dim3(64), 0, st>>>(Q.partial, p->d_locus_pichunk_offsets.p, p->T,
@@ -581,6 +594,48 @@ int tphip_pi_tables_dev(tphip_plan* p, const double* d_rates, const int32_t* d_n
         HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], (hipStream_t)stream));
     }
     return launch_pi_tables(p, d_rates, d_nres, d_tables, ws, (hipStream_t)stream, slot);
+}
+
+static PiParams pi_params(const tphip_plan* p, const double* d_rates, const int32_t* d_nres, void* ws) {
+    PiParams Q;
+    Q.rates = d_rates; Q.nres = d_nres; Q.locus_offsets = p->d_offsets.p;
+    Q.chunk_locus = p->d_pi_chunk_locus.p; Q.chunk_index = p->d_pi_chunk_index.p;
+    Q.T = p->T; Q.intervals = p->d_intervals.p; Q.n_i = p->n_i; Q.integ_mode = p->integ_mode;
+    Q.correction = p->correction; Q.threshold = p->threshold;
+    Q.round_scale = (p->round_decimals >= 0) ? std::pow(10.0, (double)p->round_decimals) : 0.0;
+    Q.partial = ws ? (double*)((char*)ws + p->ws_partial) : nullptr;
+    return Q;
+}
+
+int tphip_corrected_rates_dev(tphip_plan* p, const double* d_rates, const int32_t* d_nres, double* d_out, void* stream) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (p->ncols && (!d_rates || !d_out)) return fail(TPHIP_ERR_INVALID, "null device pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->ncols) {
+        corrected_rates_kernel<<<dim3((unsigned)((p->ncols + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+            pi_params(p, d_rates, d_nres, nullptr), p->ncols, d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return TPHIP_OK;
+}
+
+int tphip_corrected_rates(tphip_plan* p, const double* rates, const int32_t* nres, double* out) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (p->ncols == 0) return TPHIP_OK;
+    if (!rates || !out) return fail(TPHIP_ERR_INVALID, "null host pointer");
+    HIP_TRY(hipSetDevice(p->device));
+    Scratch S;
+    const size_t n = (size_t)p->ncols;
+    double* d_r = S.get<double>(n);
+    double* d_o = S.get<double>(n);
+    int32_t* d_n = nres ? S.get<int32_t>(n) : nullptr;
+    if (!d_r || !d_o || (nres && !d_n)) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_r, rates, sizeof(double) * n, hipMemcpyHostToDevice));
+    if (nres) HIP_TRY(hipMemcpy(d_n, nres, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    int rc = tphip_corrected_rates_dev(p, d_r, d_n, d_o, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return TPHIP_OK;
 }
 
 int tphip_townsend_pi_dense_dev(int32_t device, const double* d_rates, int64_t n, const double* d_times, int32_t n_times,
@@ -856,6 +911,25 @@ int tphip_quad_townsend(int32_t device, const double* rates, int64_t n, double a
     return TPHIP_OK;
 }
 
+int tphip_eval_columns_dev(tphip_plan* p, const uint8_t* d_s, const double* d_u, double* d_f, double* d_g, double* d_h,
+                           void* stream) {
+    if (!p || !d_s || !d_u || !d_f || !d_g || !d_h) return fail(TPHIP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    EvalParams E;
+    E.S.states = d_s; E.S.ncols_total = p->ncols; E.S.models = p->d_models.p; E.S.ops = p->d_ops.p;
+    E.S.nops = (int32_t)p->prog.ops.size(); E.S.stack_depth = p->prog.stack_depth; E.S.chrono_length = p->prog.chrono_length;
+    E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
+    E.S.chunk_cols = p->site_chunk_cols;
+    E.S.packed = nullptr; E.S.nwords = 0;
+    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
+    E.S.flag = nullptr; E.S.eval_counter = nullptr;
+    E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
+    const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    if (p->n_site_chunks > 0) eval_columns_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds, (hipStream_t)stream>>>(E);
+    HIP_TRY(hipGetLastError());
+    return TPHIP_OK;
+}
+
 int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, double* f, double* g, double* h) {
     if (!p || !states || !u || !f || !g || !h) return fail(TPHIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(p->device));
@@ -869,18 +943,8 @@ int tphip_eval_columns(tphip_plan* p, const uint8_t* states, const double* u, do
     if (!d_s || !d_u || !d_f || !d_g || !d_h) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
     HIP_TRY(hipMemcpy(d_s, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_u, u, sizeof(double) * n, hipMemcpyHostToDevice));
-    EvalParams E;
-    E.S.states = d_s; E.S.ncols_total = p->ncols; E.S.models = p->d_models.p; E.S.ops = p->d_ops.p;
-    E.S.nops = (int32_t)p->prog.ops.size(); E.S.stack_depth = p->prog.stack_depth; E.S.chrono_length = p->prog.chrono_length;
-    E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
-    E.S.chunk_cols = p->site_chunk_cols;
-    E.S.packed = nullptr; E.S.nwords = 0;
-    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
-    E.S.flag = nullptr; E.S.eval_counter = nullptr;
-    E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
-    const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
-    if (p->n_site_chunks > 0) eval_columns_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds>>>(E);
-    HIP_TRY(hipGetLastError());
+    int rc = tphip_eval_columns_dev(p, d_s, d_u, d_f, d_g, d_h, nullptr);
+    if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(f, d_f, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(g, d_g, sizeof(double) * n, hipMemcpyDeviceToHost));

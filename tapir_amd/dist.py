@@ -46,20 +46,28 @@ def shard_size(nloci, world):
     return (nloci + world - 1) // world
 
 
-def gather_tables(local_tables, nloci, rank, world):
+def gather_tables(local_tables, nloci, rank, world, buffers=None, always=False):
     """All-gather the per-rank [n_local, W] table blocks and undo the round-robin permutation.
 
     local_tables: torch tensor (CUDA for nccl, CPU for gloo) with the rows of shard_loci(nloci, rank, world)
-    in that order.  Returns a [nloci, W] tensor on the same device, identical on every rank."""
+    in that order.  Returns a [nloci, W] tensor on the same device, identical on every rank.
+    buffers: optional dict the padded send block and the receive buffer are kept in between calls (a hot loop then
+    allocates nothing); always: run the collective even with one rank (bench.py under a 1-rank torchrun exercises the
+    code the 8-rank run executes)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not (always and dist.is_available() and dist.is_initialized()):
         return local_tables
     per = shard_size(nloci, world)
     W = local_tables.shape[1]
-    block = torch.zeros((per, W), dtype=local_tables.dtype, device=local_tables.device)
-    block[:local_tables.shape[0]] = local_tables
-    gathered = torch.empty((world * per, W), dtype=local_tables.dtype, device=local_tables.device)
+    if buffers is not None and "block" in buffers and buffers["block"].shape == (per, W):
+        block, gathered = buffers["block"], buffers["gathered"]
+    else:
+        block = torch.zeros((per, W), dtype=local_tables.dtype, device=local_tables.device)
+        gathered = torch.empty((world * per, W), dtype=local_tables.dtype, device=local_tables.device)
+        if buffers is not None:
+            buffers["block"], buffers["gathered"] = block, gathered
+    block[:local_tables.shape[0]] = local_tables   # the padding rows (at most one per rank) stay zero
     dist.all_gather_into_tensor(gathered, block)
     # row r*per + j of `gathered` is locus j*world + r
     out = gathered.view(world, per, W).transpose(0, 1).reshape(per * world, W)

@@ -65,6 +65,9 @@ SYMBOLS = [
     ("tphip_quad_townsend", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp]),
     ("tphip_state_histogram", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp]),
     ("tphip_eval_columns", ctypes.c_int, [_vp] * 6),
+    ("tphip_eval_columns_dev", ctypes.c_int, [_vp] * 7),
+    ("tphip_corrected_rates_dev", ctypes.c_int, [_vp] * 5),
+    ("tphip_corrected_rates", ctypes.c_int, [_vp] * 4),
     ("tphip_locus_loglik", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 7),
     ("tphip_plan_set_column_weights", ctypes.c_int, [_vp, _vp]),
     ("tphip_compress_columns", ctypes.c_int, [ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -75,6 +78,30 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """Make sure the process ends up with ONE HIP/ROCr runtime whatever the import order.
+
+    A process can host one ROCr: a second copy fails to acquire the GPU's VM from KFD and its hipGetDeviceCount
+    reports no devices.  PyTorch-ROCm wheels bundle their own runtime (torch/lib/libamdhip64.so, SONAME
+    libamdhip64.so.7) and request it by the UN-versioned file name; libtphip.so requests `libamdhip64.so.7`.  When
+    torch is imported first the loader satisfies libtphip's request by SONAME from torch's copy; when libtphip.so is
+    loaded first it binds /opt/rocm's copy, torch's later request for "libamdhip64.so" matches neither that name nor
+    that SONAME, a second runtime is mapped, and torch then raises "No HIP GPUs are available" (seen in round 1 when
+    GPU tests touched the engine before torch).  Loading torch's copy by path first makes both orders the first one.
+    torch itself is not imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load libtphip.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
     global _lib
@@ -82,6 +109,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise TphipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(the engine has no CPU fallback)" % LIB_PATH)
+        _preload_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)
@@ -218,6 +246,21 @@ class Plan:
         _check(self._lib.tphip_eval_columns(self._h, states.ctypes.data, u.ctypes.data, f.ctypes.data, g.ctypes.data,
                                             h.ctypes.data))
         return f, g, h
+
+    def eval_columns_dev(self, d_states, d_u, d_f, d_g, d_h, stream=0):
+        _check(self._lib.tphip_eval_columns_dev(self._h, _ptr(d_states), _ptr(d_u), _ptr(d_f), _ptr(d_g), _ptr(d_h), stream))
+
+    def corrected_rates(self, rates, nres=None):
+        """parse_site_rates (+ cull when nres is given) as the PI stage applies them: round4(rate) / correction."""
+        rates = _np(rates, np.float64)
+        assert rates.shape == (self.ncols,)
+        nres = None if nres is None else _np(nres, np.int32)
+        out = np.empty(self.ncols)
+        _check(self._lib.tphip_corrected_rates(self._h, rates.ctypes.data, _ptr(nres), out.ctypes.data))
+        return out
+
+    def corrected_rates_dev(self, d_rates, d_nres, d_out, stream=0):
+        _check(self._lib.tphip_corrected_rates_dev(self._h, _ptr(d_rates), _ptr(d_nres), _ptr(d_out), stream))
 
     def locus_loglik(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
                      cand_pfac=None, cache=None):

@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-from . import nexus
+from . import compute, nexus
 
 
 class PipelineError(Exception):
@@ -23,14 +23,47 @@ def _read_one(path):
     return nexus.read_states(path)
 
 
-def load_alignments(paths, leaf_names, workers=1):
+class HostPool:
+    """Worker processes for the host-side text work of a run (NEXUS parsing, `.rates` JSON formatting) -- the part of
+    `Pool(cpu_count() - 1).map(worker, params)` (bin/tapir_compute.py:159-164) that is still CPU work here.
+
+    The pool is forked ONCE, by the caller, BEFORE the process touches the GPU (before torch.distributed /
+    RCCL come up and before libtphip's first call): forking a process that holds a HIP context and RCCL's threads
+    hands the children KFD file descriptors and possibly held locks.  Results that do not exist yet at fork time (the
+    per-site arrays the writers format) reach the workers through files in /dev/shm that they map read-only."""
+
+    def __init__(self, workers):
+        import multiprocessing
+        self.workers = int(workers)
+        self._pool = multiprocessing.get_context("fork").Pool(self.workers)
+
+    def parse(self, paths):
+        return self._pool.map(_read_one, paths, chunksize=max(1, len(paths) // (8 * self.workers)))
+
+    def write_rates(self, jobs, progress=None):
+        for _ in self._pool.imap_unordered(_write_job, jobs, chunksize=max(1, len(jobs) // (8 * self.workers))):
+            if progress:
+                progress()
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.close()
+            self._pool.join()
+            self._pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def load_alignments(paths, leaf_names, pool=None):
     """Read NEXUS alignments and flatten them: returns (states uint8 [ntaxa, ncols_total], offsets int64[L+1]).
     Rows follow `leaf_names` (the tree's leaves); an alignment must hold exactly those taxa, as HyPhy
-    requires of (siteFilter, siteTree).  workers > 1 parses files in a process pool (--multiprocessing)."""
-    if workers > 1 and len(paths) > 1:
-        import multiprocessing
-        with multiprocessing.get_context("fork").Pool(workers) as pool:
-            parsed = pool.map(_read_one, paths, chunksize=max(1, len(paths) // (8 * workers)))
+    requires of (siteFilter, siteTree).  pool: a HostPool parses the files in parallel (--multiprocessing)."""
+    if pool is not None and len(paths) > 1:
+        parsed = pool.parse(paths)
     else:
         parsed = [_read_one(p) for p in paths]
     blocks, offsets = [], [0]
@@ -83,16 +116,28 @@ def dumps_rates_json(freqs, exch, site, subst, rate, ll, corrected):
     return head + body + "    }\n}"
 
 
-_WRITE_CTX = None
+def _write_rates_file(path, freqs, exch, subst, rate4, lnl, corrected):
+    n = len(subst)
+    with open(path, "w") as fh:
+        fh.write(dumps_rates_json(freqs, exch, np.arange(1, n + 1), subst, rate4, lnl, corrected))
 
 
-def _write_one(l):
-    alignments, offsets, pi, exch, subst, rate4, lnl, corrected, output_dir = _WRITE_CTX
-    sl = slice(offsets[l], offsets[l + 1])
-    n = offsets[l + 1] - offsets[l]
-    with open(os.path.join(output_dir, os.path.basename(alignments[l]) + ".rates"), "w") as fh:
-        fh.write(dumps_rates_json(pi[l], exch[l], np.arange(1, n + 1), subst[sl], rate4[sl], lnl[sl], corrected[sl]))
-    return l
+_SHARED_VIEWS = {}
+
+
+def _write_job(job):
+    """Pool worker: format one locus' .rates file from the per-site arrays the parent left in a shared file."""
+    path, shared, total, a, b, freqs, exch = job
+    arr = _SHARED_VIEWS.get(shared)
+    if arr is None:
+        _SHARED_VIEWS.clear()   # one run at a time: drop the mapping of a previous run
+        arr = _SHARED_VIEWS[shared] = np.memmap(shared, dtype=np.float64, mode="r", shape=(4, total))
+    _write_rates_file(path, freqs, exch, arr[0, a:b], arr[1, a:b], arr[2, a:b], arr[3, a:b])
+    return path
+
+
+def _shared_dir():
+    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
 
 STAGE1_BLOCK_LOCI = 512   # loci fitted together: 512 x 202 models x 9-point stencils = 0.9 M candidates per call
@@ -128,17 +173,18 @@ def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, bl
 
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
                    exch, pi=None, subsets=None, output_dir=None, device=0, integ_mode=0, round_decimals=4,
-                   engine_mod=None, progress=None, workers=1, cat_rates=None, cat_weights=None):
+                   engine_mod=None, progress=None, pool=None, cat_rates=None, cat_weights=None):
     """Site rates + PI for a list of NEXUS alignments.  Returns a list of worker()-shaped tuples
     (alignment, rates, mean_rate, None, pi_net, pi_times, pi_epochs) in the order of `alignments`.
 
     exch: [6] or [L,6] exchangeabilities AC,AG,AT,CG,CT,GT, or None = HyPhy's stage 1 (model-averaged estimates per
-    locus, tapir_amd/stage1.py); pi: None (empirical, HarvestFrequencies) or [L,4]."""
+    locus, tapir_amd/stage1.py); pi: None (empirical, HarvestFrequencies) or [L,4].
+    pool: a HostPool created before the process touched the GPU (parallel parsing and .rates writing), or None."""
     eng = engine_mod
     if eng is None:
         from . import engine as eng
     subsets = subsets or {}
-    states, offsets = load_alignments(alignments, leaf_names, workers)
+    states, offsets = load_alignments(alignments, leaf_names, pool)
     L = len(alignments)
     if pi is None:
         hist = eng.state_histogram(states, offsets, device=device)
@@ -163,7 +209,7 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     finally:
         plan.close()
     # what tapir would have after parse_site_rates + cull (bin/tapir_compute.py:100-102)
-    rate4 = np.round(out["rate"] * 10.0 ** round_decimals) / 10.0 ** round_decimals if round_decimals >= 0 else out["rate"]
+    rate4 = compute.round_like_hyphy(out["rate"], round_decimals) if round_decimals >= 0 else out["rate"]
     corrected = rate4 / correction
     culled = np.where(out["nres"] >= threshold, corrected, np.nan)
     per_locus = []
@@ -174,22 +220,28 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
             r = r[subsets[base][0]:subsets[base][1]]
         per_locus.append(r)
     if output_dir is not None:
-        global _WRITE_CTX
-        _WRITE_CTX = (alignments, offsets, pi, exch, out["subst"], rate4, out["lnl"], corrected, output_dir)
-        if workers > 1 and L > 1:
-            import multiprocessing
-            # forked AFTER the results exist: the children inherit the arrays, only format text and write
-            # files, and never touch the GPU runtime
-            with multiprocessing.get_context("fork").Pool(workers) as pool:
-                for _ in pool.imap_unordered(_write_one, range(L), chunksize=max(1, L // (8 * workers))):
-                    if progress:
-                        progress()
+        paths = [os.path.join(output_dir, os.path.basename(a) + ".rates") for a in alignments]
+        if pool is not None and L > 1:
+            import tempfile
+            # the workers were forked before these arrays existed: hand them over through one shared file
+            fd, shared = tempfile.mkstemp(prefix="tapir_amd_", suffix=".f64", dir=_shared_dir())
+            os.close(fd)
+            try:
+                total = int(offsets[-1])
+                arr = np.memmap(shared, dtype=np.float64, mode="w+", shape=(4, max(total, 1)))
+                arr[0, :total], arr[1, :total], arr[2, :total], arr[3, :total] = out["subst"], rate4, out["lnl"], corrected
+                arr.flush()
+                jobs = [(paths[l], shared, max(total, 1), int(offsets[l]), int(offsets[l + 1]), pi[l], exch[l]) for l in range(L)]
+                pool.write_rates(jobs, progress)
+                del arr
+            finally:
+                os.unlink(shared)
         else:
             for l in range(L):
-                _write_one(l)
+                sl = slice(offsets[l], offsets[l + 1])
+                _write_rates_file(paths[l], pi[l], exch[l], out["subst"][sl], rate4[sl], out["lnl"][sl], corrected[sl])
                 if progress:
                     progress()
-        _WRITE_CTX = None
     elif progress:
         for _ in alignments:
             progress()

@@ -14,19 +14,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def pytest_collection_modifyitems(config, items):
-    """GPU sessions: bring torch's HIP context up before any test touches the device through libtphip.  (Seen once on
-    the GPU box: torch initialising AFTER a long run of library calls and GPU subprocesses in the same process reported
-    "No HIP GPUs are available"; in collection order it never does, and this removes the dependence on order.)"""
-    if any(item.get_closest_marker("gpu") for item in items):
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
-        except Exception:
-            pass
-
-
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(GOLDEN, "reference_compute_outputs.npz"))

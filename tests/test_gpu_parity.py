@@ -248,8 +248,104 @@ def test_plan_rejects_bad_arguments(chr1_918):
         engine.Plan(*args, [10], [[10, 10]])
     with pytest.raises(engine.TphipError, match="post-order"):
         engine.Plan(5, c["parent"][::-1].copy(), c["blen"], c["leaf"], [0, 226], [c["pi"]], [c["exch"]], 174, [1], [[0, 1]])
-    with pytest.raises(engine.TphipError, match="frequencies"):
-        engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, 226], [[0.5, 0.5, 0.0, 0.0]], [c["exch"]], 174, [1], [[0, 1]])
+    with pytest.raises(engine.TphipError, match="fewer than two bases"):
+        engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, 226], [[1.0, 0.0, 0.0, 0.0]], [c["exch"]], 174, [1], [[0, 1]])
+    with pytest.raises(engine.TphipError, match="frequencies of locus 0"):
+        engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, 226], [[0.5, 0.6, -0.1, 0.0]], [c["exch"]], 174, [1], [[0, 1]])
+
+
+def test_locus_with_an_absent_base(oracle):
+    """A short gap-free locus in which one base never occurs has empirical frequency 0 for it (HarvestFrequencies,
+    bf:968); HyPhy fits such a locus, so the plan must accept it (it used to abort the whole batch).  The engine floors
+    the zero at 1e-12 of the total (tphip.hip: kPiFloor); checked against the oracle on the same floored frequencies,
+    and the floor itself is shown not to matter: the oracle's log L moves by < 1e-8 between floors of 1e-12 and 1e-9."""
+    engine = _engine()
+    from tapir_amd import nexus, synth
+    d = synth.simulate(2, 400, 12, 77, gap_frac=0.0)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy().copy()
+    a = st[:, :400]
+    a[a == 8] = 1                                        # locus 0: every T becomes an A -> pi_T = 0
+    hist = engine.state_histogram(st, d["locus_offsets"])
+    pi = nexus.base_frequencies_from_histogram(hist)
+    assert pi[0, 3] == 0.0 and (pi[1] > 0).all()
+    plan = engine.Plan(12, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, d["exch"], pin["T"], [10], [[5, 15]],
+                       correction=pin["correction"])
+    got = plan.run_fused(st)
+    assert np.isfinite(got["tables"]).all() and np.isfinite(got["lnl"]).all()
+    kappa = plan.models()[3]
+
+    def floored(p, eps):
+        q = np.maximum(p, eps * p.sum())
+        return q / q.sum()
+
+    for l in range(2):
+        sl = slice(l * 400, (l + 1) * 400)
+        ref = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], floored(pi[l], 1e-12), d["exch"][l])
+        assert np.array_equal(got["flag"][sl], ref["flag"])
+        assert np.abs(got["lnl"][sl] - ref["lnl"]).max() < 1e-9
+        _assert_rates_match(oracle, got, ref, sl, st[:, sl], pin, floored(pi[l], 1e-12), d["exch"][l], kappa[l])
+    coarse = oracle.site_rates(st[:, :400], pin["parent"], pin["blen"], pin["leaf"], floored(pi[0], 1e-9), d["exch"][0])
+    fine = oracle.site_rates(st[:, :400], pin["parent"], pin["blen"], pin["leaf"], floored(pi[0], 1e-12), d["exch"][0])
+    assert np.abs(coarse["lnl"] - fine["lnl"]).max() < 1e-8
+    plan.close()
+
+
+def test_four_decimal_round_trip_matches_printf_on_ties(chr1_918):
+    """The rate the PI stage uses is what tapir reads back from HyPhy's Format(x,0,4) text (bf:1093-1095): printf-style
+    rounding of the EXACT binary value.  Constructed near-ties: doubles next to (k + 0.5) * 1e-4, whose product with
+    1e4 rounds onto the half-integer although the true product is above or below it -- rint(r * 1e4) / 1e4 (round 1)
+    gets about half of them wrong by 1e-4.  Device (tphip_corrected_rates) and host helper against "%.4f"."""
+    engine = _engine()
+    from tapir_amd import compute
+    c = chr1_918
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 10 ** 7, 20000)
+    v = (k + 0.5) / 1e4
+    v = np.concatenate([v, np.nextafter(v, np.inf), np.nextafter(v, -np.inf), rng.gamma(0.5, 0.02, 20000),
+                        [0.03125, 0.09375, 0.00005, 1.00015, 0.0, 2.5e-5, 9999.99995, 1e4]])
+    want = np.array([float("%.4f" % x) for x in v])
+    naive = np.round(v * 1e4) / 1e4
+    assert (naive != want).sum() > 1000                  # the cases are real
+    assert np.array_equal(compute.round_like_hyphy(v, 4), want)
+    n = v.size
+    plan = engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, n], [c["pi"]], [c["exch"]], 174, [10], [[0, 10]],
+                       correction=100.0, threshold=3, round_decimals=4)
+    got = plan.corrected_rates(v)
+    assert np.array_equal(got, want / 100.0)
+    nres = np.where(np.arange(n) % 3 == 0, 2, 3).astype(np.int32)
+    got = plan.corrected_rates(v, nres)
+    assert np.isnan(got[nres < 3]).all() and np.array_equal(got[nres >= 3], (want / 100.0)[nres >= 3])
+    plan.close()
+    raw = engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, n], [c["pi"]], [c["exch"]], 174, [10], [[0, 10]],
+                      correction=100.0, round_decimals=-1)
+    assert np.array_equal(raw.corrected_rates(v), v / 100.0)
+    raw.close()
+
+
+def test_engine_before_torch_in_one_process():
+    """Round 1 saw torch report "No HIP GPUs are available" when it initialised after libtphip in the same process: the
+    library had bound /opt/rocm's HIP runtime, torch then mapped its bundled copy, and the second ROCr in a process
+    cannot acquire the GPU.  engine.load() now loads torch's copy first (engine._preload_torch_hip_runtime); this runs
+    the failing order in a fresh process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tapir_amd import engine\n"
+            "assert engine.device_count() >= 1\n"
+            "import numpy as np\n"
+            "pi = engine.townsend_pi_dense([1.0, 2.0], [0.1, 0.2])\n"
+            "assert np.isfinite(pi).all()\n"
+            "import torch\n"
+            "torch.cuda.init()\n"
+            "x = torch.ones(4, device='cuda') * 2\n"
+            "assert float(x.sum()) == 8.0\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "libs = {l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}\n"
+            "assert len(libs) == 1, libs\n"
+            "print('ok')\n") % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout, r.stderr[-3000:])
 
 
 def test_all_gap_and_ragged_loci(oracle):

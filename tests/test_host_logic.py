@@ -317,6 +317,48 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.tphip_version() == 100
 
 
+def test_one_hip_runtime_whatever_the_import_order():
+    """engine.load() before `import torch` must not leave two HIP runtimes in the process (the cause of round 1's
+    "No HIP GPUs are available": see engine._preload_torch_hip_runtime).  Needs no GPU: it reads the process' map."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from tapir_amd import engine\n"
+            "engine.load()\n"
+            "import torch\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "for stem in ('libamdhip64', 'libhsa-runtime64'):\n"
+            "    libs = {l.split()[-1] for l in maps.splitlines() if stem in l}\n"
+            "    assert len(libs) == 1, libs\n"
+            "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout, r.stderr[-3000:])
+
+
+def test_round_like_hyphy_is_the_printf_round_trip():
+    """Host twin of the device rounding (csrc/pi_kernels.hpp round_like_printf): float("%.4f" % x) on constructed
+    near-ties, where numpy.round(x * 1e4) / 1e4 is wrong about half the time."""
+    from tapir_amd import compute
+    rng = np.random.default_rng(2)
+    k = rng.integers(0, 10 ** 8, 50000)
+    v = (k + 0.5) / 1e4
+    v = np.concatenate([v, np.nextafter(v, np.inf), np.nextafter(v, -np.inf), rng.gamma(0.5, 0.02, 20000),
+                        [0.03125, 0.09375, 0.00005, 1.00015, 0.0, 2.5e-5]])
+    want = np.array([float("%.4f" % x) for x in v])
+    assert np.array_equal(compute.round_like_hyphy(v, 4), want)
+    assert (np.round(v * 1e4) / 1e4 != want).sum() > 10000
+    assert np.array_equal(compute.round_like_hyphy(v.reshape(2, -1), 4), want.reshape(2, -1))
+    assert np.array_equal(compute.round_like_hyphy([0.125, 0.375], 2), [0.12, 0.38])   # exact ties: to even, as printf
+
+
+def test_absent_base_has_zero_frequency():
+    """A gap-free locus over three bases gives pi = 0 for the fourth (HarvestFrequencies); the plan accepts it
+    (GPU test test_locus_with_an_absent_base)."""
+    from tapir_amd import nexus
+    hist = np.zeros((1, 16), np.int64)
+    hist[0, 1], hist[0, 2], hist[0, 4] = 10, 20, 30
+    pi = nexus.base_frequencies_from_histogram(hist)
+    assert pi[0, 3] == 0.0 and abs(pi[0].sum() - 1) < 1e-15
+
+
 def test_engine_fails_loudly_without_gpu(chr1_918):
     """No silent CPU fallback: on a GPU-less machine plan creation raises with TPHIP_ERR_NO_DEVICE."""
     from tapir_amd import engine
