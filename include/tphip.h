@@ -63,6 +63,15 @@ enum {
     TPHIP_INTEG_CLOSED = 1    /* analytic antiderivative -(4rt+1)exp(-4rt); error column = 0            */
 };
 
+/* tphip_plan_desc.start_rule */
+enum {
+    TPHIP_START_PARSIMONY = 0, /* the column's parsimony rate (default)                                */
+    TPHIP_START_REFERENCE = 1  /* siteRate = 1, HyPhy's start value (bf:1050)                          */
+};
+
+/* tphip_plan_desc.pattern_dedup */
+enum { TPHIP_DEDUP_AUTO = 0, TPHIP_DEDUP_OFF = 1, TPHIP_DEDUP_ON = 2 };
+
 int tphip_version(void);
 const char *tphip_last_error(void);
 /* number of usable HIP devices (0 if none; never fails) */
@@ -107,6 +116,17 @@ typedef struct tphip_plan_desc {
     int32_t ncat;              /* number of categories, at most 16                                    */
     const double *cat_rate;    /* [ncat] rate multipliers > 0 (mean 1 keeps `rate` = kappa * s interpretable) */
     const double *cat_weight;  /* [ncat] weights > 0 (normalised by the library)                       */
+    /* Where the per-site optimiser starts.  HyPhy starts every column at siteRate = 1 (bf:1050) and returns the local
+     * optimum uphill of that point.  TPHIP_START_PARSIMONY starts at the column's parsimony rate instead:
+     * one evaluation fewer per column and the same maximum on every unimodal column; on the rare multimodal ones
+     * (measured: 0 of 4e5 columns at 64 taxa, 6e-5 at 16 taxa, 1e-3 of noisy 5-taxon columns: DESIGN.md section 5)
+     * it may end on another local optimum than a search from 1 would.  TPHIP_START_REFERENCE starts at siteRate = 1. */
+    int32_t start_rule;        /* TPHIP_START_*                                                        */
+    /* HyPhy fits one rate per UNIQUE column pattern of a locus and reports it for every column that carries it
+     * (bf:1033-1044: GetDataInfo(dupInfo...), alreadyDone[siteMap]).  TPHIP_DEDUP_AUTO does the same wherever a cheap
+     * per-locus estimate says at least ~15 % of the columns that need the optimiser are repeats (real loci; the synthetic
+     * alignments with random gaps hardly repeat a column); ON / OFF force it.  The outputs are bit-identical either way. */
+    int32_t pattern_dedup;     /* TPHIP_DEDUP_*                                                        */
 } tphip_plan_desc;
 
 int tphip_plan_create(const tphip_plan_desc *desc, tphip_plan **out);

@@ -260,9 +260,12 @@ def correct_branch_lengths_values(newick_text):
 # ctypes wrappers over tapir_oracle.c
 # --------------------------------------------------------------------------------------------------
 
-def site_rates(states, parent, blen, leaf_taxon, pi, exch, cat_rates=None, cat_weights=None):
+def site_rates(states, parent, blen, leaf_taxon, pi, exch, cat_rates=None, cat_weights=None, start_mode=0):
     """HyPhy stage 2 restatement for one locus. states: uint8 [ntaxa, ncols] masks.
     cat_rates / cat_weights: optional discrete rate mixture on top of the site rate (not in the reference).
+    start_mode: 0 = the optimiser the product uses (parsimony start, accelerated exits); 1 = reference-faithful:
+    every column starts at siteRate = 1 (models_and_rates.bf:1050), plain safeguarded Newton to 1e-12; 2 = the
+    product's step rule and exits started at siteRate = 1 (the engine's start_rule = 1).
     Returns dict(rate, subst, lnl, flag, nres, nevals)."""
     states = np.ascontiguousarray(states, dtype=np.uint8)
     ntaxa, ncols = states.shape
@@ -282,6 +285,14 @@ def site_rates(states, parent, blen, leaf_taxon, pi, exch, cat_rates=None, cat_w
                 parent.ctypes.data_as(_c_i32p), _dp(blen), leaf_taxon.ctypes.data_as(_c_i32p), _dp(pi), _dp(exch),
                 ctypes.c_int32(len(cr)), _dp(cr), _dp(cw), _dp(rate), _dp(subst), _dp(lnl),
                 flag.ctypes.data_as(_c_u8p), nres.ctypes.data_as(_c_i32p))
+        return dict(rate=rate, subst=subst, lnl=lnl, flag=flag, nres=nres, nevals=int(ne))
+    if start_mode:
+        fn = lib().orc_site_rates_mode
+        fn.restype = ctypes.c_int64
+        ne = fn(states.ctypes.data_as(_c_u8p), ctypes.c_int64(ncols), ctypes.c_int32(ntaxa), ctypes.c_int32(len(parent)),
+                parent.ctypes.data_as(_c_i32p), _dp(blen), leaf_taxon.ctypes.data_as(_c_i32p), _dp(pi), _dp(exch),
+                ctypes.c_int32(int(start_mode)), _dp(rate), _dp(subst), _dp(lnl), flag.ctypes.data_as(_c_u8p),
+                nres.ctypes.data_as(_c_i32p))
         return dict(rate=rate, subst=subst, lnl=lnl, flag=flag, nres=nres, nevals=int(ne))
     ne = lib().orc_site_rates(states.ctypes.data_as(_c_u8p), ncols, ntaxa, len(parent),
                               parent.ctypes.data_as(_c_i32p), _dp(blen), leaf_taxon.ctypes.data_as(_c_i32p),

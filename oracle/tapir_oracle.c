@@ -813,12 +813,58 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
     *f_out = f;
 }
 
+/* REFERENCE-FAITHFUL MODE (start_mode = 1): what the script literally asks HyPhy for -- every column starts at
+ * siteRate = 1 (bf:1050) and Optimize() climbs from there (bf:1053) -- restated with nothing borrowed from the product's
+ * accelerated optimiser: start u = log 1 = 0, plain Newton step -f'/f'' where f is concave (a capped step uphill where
+ * it is not), bracket safeguard, iterate until the step is below 1e-12.  No parsimony start, no log-step refinement, no
+ * plateau stride, no Hermite / third-order exits.  Only the reporting POLICY is shared with the default mode (DESIGN.md
+ * section 5: when a column counts as saturated, the s = 1e4 policy value, the confirmation by value beyond s = 20), so
+ * that the two modes are comparable column by column: a difference in `rate` between them is a different local optimum
+ * (or an inaccurate accelerated exit), nothing else.  SURVEY F4: HyPhy returns the local optimum uphill of its start. */
+static void maximise_column_plain(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
+                                  double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
+    double u = 0.0, lo = ORC_U_MIN, hi = ORC_U_MAX, f = 0, g, h;
+    int lo_open = 1, hi_open = 1;
+    *flag_out = 4;
+    for (int it = 0; it < 4 * ORC_MAXIT; ++it) {
+        column_loglik(m, tr, states, ncols, col, u, &f, &g, &h);
+        ++*neval;
+        int uphill = !(g <= 0);
+        if (fabs(g) < ORC_FLAT_EPS && fabs(h) < ORC_FLAT_EPS) { *flag_out = 2; u = ORC_U_MAX; break; }
+        if (u >= ORC_U_MAX && uphill) { *flag_out = 2; break; }
+        if (u <= ORC_U_MIN && !uphill) { *flag_out = 3; break; }
+        if (uphill) { lo = u; lo_open = 0; } else { hi = u; hi_open = 0; }
+        double step = (h < 0) ? -g / h : (uphill ? ORC_STEP_MAX : -ORC_STEP_MAX);
+        if (!(step <= ORC_STEP_MAX)) step = ORC_STEP_MAX;
+        if (step < -ORC_STEP_MAX) step = -ORC_STEP_MAX;
+        double un = u + step;
+        if (fabs(step) >= 1e-12) {
+            if (un >= hi) un = hi_open ? ORC_U_MAX : 0.5 * (lo + hi);
+            else if (un <= lo) un = lo_open ? ORC_U_MIN : 0.5 * (lo + hi);
+            /* a bracket that has closed to rounding is convergence too */
+            if (!(hi_open || lo_open) && hi - lo < 1e-12) { step = 0.0; un = u; }
+            else { u = un; continue; }
+        }
+        u = un;
+        *flag_out = 0;
+        if (u >= ORC_U_CHECK) {
+            double fm, gm, hm;
+            column_loglik(m, tr, states, ncols, col, ORC_U_MAX, &fm, &gm, &hm);
+            ++*neval;
+            if (fm >= f - ORC_SAT_TOL * fmax(1.0, fabs(f))) { *flag_out = 2; u = ORC_U_MAX; f = fm; }
+        }
+        break;
+    }
+    *s_out = exp(u);
+    *f_out = f;
+}
+
 /* One locus.  Outputs per column: rate = kappa*s (bf:1061), subst = rate*chronoLength (bf:1056-1060),
  * lnl, flag, nres = number of plain A/C/G/T cells (tapir/compute.py:104). Returns total evaluations. */
-int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
-                           const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
-                           int32_t ncat, const double *cat_rate, const double *cat_weight,
-                           double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
+static int64_t site_rates_impl(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                               const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
+                               int32_t ncat, const double *cat_rate, const double *cat_weight, int32_t start_mode,
+                               double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
     orc_model m;
     orc_tree tr = {nnodes, ntaxa, parent, leaf_taxon, blen, NULL};
     int64_t total_eval = 0;
@@ -851,6 +897,10 @@ int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, 
             /* every resolved taxon carries the same base x: L(s) <= pi_x = L(0), optimum at s = 0 */
             int x = (uni == 1) ? 0 : (uni == 2) ? 1 : (uni == 4) ? 2 : 3;
             s = 0.0; f = log(m.pi[x]); fl = 3;
+        } else if (start_mode == 1) {
+            maximise_column_plain(&m, &tr, states, ncols, c, &s, &f, &fl, &ne);
+        } else if (start_mode == 2) { /* HyPhy's start value, the product's step rule and exits (tphip_plan_desc.start_rule = 1) */
+            maximise_column(&m, &tr, states, ncols, c, 0.0, &s, &f, &fl, &ne);
         } else {
             maximise_column(&m, &tr, states, ncols, c, fitch_start(&m, &tr, kids, first, states, ncols, c, chrono, resolved), &s, &f, &fl, &ne);
         }
@@ -865,11 +915,29 @@ int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, 
     return total_eval;
 }
 
+int64_t orc_site_rates_mix(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                           const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
+                           int32_t ncat, const double *cat_rate, const double *cat_weight,
+                           double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
+    return site_rates_impl(states, ncols, ntaxa, nnodes, parent, blen, leaf_taxon, pi, exch, ncat, cat_rate, cat_weight, 0, rate,
+                           subst, lnl, flag, nres_out);
+}
+
 int64_t orc_site_rates(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
                        const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
                        double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
-    return orc_site_rates_mix(states, ncols, ntaxa, nnodes, parent, blen, leaf_taxon, pi, exch, 0, NULL, NULL, rate, subst, lnl,
-                              flag, nres_out);
+    return site_rates_impl(states, ncols, ntaxa, nnodes, parent, blen, leaf_taxon, pi, exch, 0, NULL, NULL, 0, rate, subst, lnl,
+                           flag, nres_out);
+}
+
+/* start_mode 0: the product's optimiser (parsimony start, accelerated exits); 1: the reference-faithful restatement
+ * (start at siteRate = 1, plain Newton to 1e-12; see maximise_column_plain); 2: the product's optimiser started at
+ * siteRate = 1 (what the engine runs with start_rule = 1) */
+int64_t orc_site_rates_mode(const uint8_t *states, int64_t ncols, int32_t ntaxa, int32_t nnodes, const int32_t *parent,
+                            const double *blen, const int32_t *leaf_taxon, const double *pi, const double *exch,
+                            int32_t start_mode, double *rate, double *subst, double *lnl, uint8_t *flag, int32_t *nres_out) {
+    return site_rates_impl(states, ncols, ntaxa, nnodes, parent, blen, leaf_taxon, pi, exch, 0, NULL, NULL, start_mode, rate,
+                           subst, lnl, flag, nres_out);
 }
 
 /* log-likelihood curve of one column at given u values (used by tests to check derivatives) */

@@ -70,6 +70,10 @@ def get_args(argv=None):
                      help="K > 1: discrete-gamma mixture of K rate categories on top of each site's rate (GTR+G; the "
                           "reference's HyPhy script has none, so K = 1 is the drop-in setting)")
     new.add_argument('--gamma-alpha', type=float, default=0.5, help="shape of that gamma distribution")
+    new.add_argument('--reference-start', action='store_true',
+                     help="start every site's optimiser at siteRate = 1 as the HyPhy script does (models_and_rates.bf:1050) "
+                          "instead of at the site's parsimony rate: identical on unimodal sites, and on the rare multimodal "
+                          "ones the optimum uphill of HyPhy's start; costs about one likelihood evaluation per site")
     new.add_argument('--full-precision-rates', action='store_true',
                      help="do not round site rates to 4 decimals before PI (the reference rounds through its JSON file)")
     return parser.parse_args(argv)
@@ -206,7 +210,8 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
                                                output_dir=args.output, device=args.device, integ_mode=integ_mode,
                                                round_decimals=-1 if args.full_precision_rates else 4,
                                                engine_mod=engine_mod, progress=progress, pool=pool,
-                                               cat_rates=cat_rates, cat_weights=cat_weights)
+                                               cat_rates=cat_rates, cat_weights=cat_weights,
+                                               start_rule=1 if args.reference_start else 0)
             tables = out["final_tables"]
         else:
             pis, tables = [], np.zeros((0, W))

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "tphip.h"
 
 namespace tphip {
 
@@ -124,6 +125,150 @@ __global__ void pattern_offsets_kernel(const int64_t* off, int64_t nloci, int64_
 __global__ void count_to_weight_kernel(const int32_t* count, int64_t npat, double* weight) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < npat) weight[p] = (double)count[p];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stage 2 (per-site rates): optimise one rate per unique pattern (bf:1033-1044: `GetDataInfo(dupInfo...)`,
+// `alreadyDone[siteMap]`) and copy it to the pattern's other columns.  Everything stays in the hot path's own pass:
+//
+//   classify_kernel       also leaves a 64-bit hash of every column's packed tip words (pi_kernels.hpp);
+//   dedup_estimate_kernel one workgroup per locus: a 64 Ki-bit LDS bitmap of the work columns' hashes estimates the
+//                         number of distinct patterns (linear counting); the locus is de-duplicated only if that
+//                         estimate is below kDedupWorthIt of its work columns (synthetic alignments with random gaps
+//                         hardly repeat a column: they skip the rest of this machinery), and then clears its slice of
+//                         the hash table;
+//   dedup_insert_kernel   work column -> open-addressing table of its locus (atomicCAS on the hash, atomicMin on the
+//                         column index: the representative of a pattern is its FIRST column, whatever the schedule);
+//   dedup_resolve_kernel  a work column whose table entry names another column compares its packed words with that
+//                         column's (exact: a hash collision only costs the saving) and, if equal, leaves the work
+//                         list: flag = kFlagDuplicate, dup_of = representative;
+//   (compact / scan / site_rate_kernel run on what is left)
+//   dedup_scatter_kernel  copies (rate, subst, lnL, flag) from the representative.
+//
+// Results are bit-identical with and without de-duplication: a column's answer depends only on its packed words and
+// its locus' model (tests: test_results_do_not_depend_on_how_the_work_list_is_shared_out, test_stage2_pattern_dedup).
+// Byte/integer work, HBM- and atomics-bound: 8 B hash + 4 B dup_of per column, 24 B of table per column of a
+// de-duplicated locus.
+constexpr uint8_t kFlagDuplicate = 0x40;      // internal: never leaves launch_site_rates
+constexpr unsigned long long kDedupEmpty = ~0ull;
+constexpr int kDedupBitmapBits = 1 << 16;
+constexpr double kDedupWorthIt = 0.85;
+constexpr int kDedupMinColumns = 32;
+enum : int32_t { DEDUP_AUTO = 0, DEDUP_OFF = 1, DEDUP_ON = 2 };
+
+struct DedupParams {
+    const int64_t* locus_offsets;   // [nloci+1]
+    const int32_t* chunk_locus;     // 1024-column chunks (the PI chunk tables)
+    const int32_t* chunk_index;
+    const uint64_t* hash;           // [ncols] from classify_kernel
+    const uint32_t* packed;         // [nwords][ncols]
+    int32_t nwords;
+    int64_t ncols_total;
+    uint8_t* flag;                  // [ncols]
+    int32_t* dup_of;                // [ncols] representative column, or -1
+    unsigned long long* tab_key;    // [2 * ncols]; locus l owns [2 * lo, 2 * hi)
+    int32_t* tab_val;               // [2 * ncols] smallest column (locus-relative) carrying the hash
+    int32_t* on;                    // [nloci] 1 = this locus is de-duplicated in this launch
+    int32_t mode;                   // DEDUP_*
+    double* rate; double* subst; double* lnl;
+};
+
+__device__ __forceinline__ unsigned long long dedup_key(uint64_t h) { return h == kDedupEmpty ? 0ull : h; }
+
+__global__ __launch_bounds__(256) void dedup_estimate_kernel(DedupParams P) {
+    __shared__ unsigned bitmap[kDedupBitmapBits / 32];
+    __shared__ int counts[2];
+    const int locus = blockIdx.x;
+    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+    for (int i = threadIdx.x; i < kDedupBitmapBits / 32; i += blockDim.x) bitmap[i] = 0u;
+    if (threadIdx.x < 2) counts[threadIdx.x] = 0;
+    __syncthreads();
+    // a prefix of the locus is enough for the estimate (and keeps the bitmap's load below ~1.5)
+    const int64_t end = (hi - lo > 3 * (int64_t)kDedupBitmapBits / 2) ? lo + 3 * (int64_t)kDedupBitmapBits / 2 : hi;
+    int mine = 0;
+    for (int64_t c = lo + threadIdx.x; c < end; c += blockDim.x) {
+        if (P.flag[c] != TPHIP_FLAG_OK) continue;
+        ++mine;
+        const unsigned b = (unsigned)(P.hash[c] >> 17) & (kDedupBitmapBits - 1);
+        atomicOr(&bitmap[b >> 5], 1u << (b & 31));
+    }
+    atomicAdd(&counts[0], mine);
+    __syncthreads();
+    int bits = 0;
+    for (int i = threadIdx.x; i < kDedupBitmapBits / 32; i += blockDim.x) bits += __popc(bitmap[i]);
+    atomicAdd(&counts[1], bits);
+    __syncthreads();
+    const int n = counts[0];
+    const double fill = (double)counts[1] / (double)kDedupBitmapBits;
+    const double distinct = (fill < 1.0) ? -(double)kDedupBitmapBits * log(1.0 - fill) : 1e300;   // linear counting
+    const bool on = P.mode == DEDUP_ON || (P.mode == DEDUP_AUTO && n >= kDedupMinColumns && distinct <= kDedupWorthIt * (double)n);
+    if (threadIdx.x == 0) P.on[locus] = on ? 1 : 0;
+    if (on) {
+        for (int64_t i = 2 * lo + threadIdx.x; i < 2 * hi; i += blockDim.x) { P.tab_key[i] = kDedupEmpty; P.tab_val[i] = 0x7fffffff; }
+    }
+}
+
+// thread = column (1024-column chunks of one locus, 4 columns per thread strided by the block size)
+__global__ __launch_bounds__(256) void dedup_insert_kernel(DedupParams P) {
+    const int locus = P.chunk_locus[blockIdx.x];
+    if (!P.on[locus]) return;
+    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+    const int64_t base = lo + (int64_t)P.chunk_index[blockIdx.x] * 1024;
+    const unsigned long long size = 2ull * (unsigned long long)(hi - lo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t c = base + j * 256 + threadIdx.x;
+        if (c >= hi || P.flag[c] != TPHIP_FLAG_OK) continue;
+        const unsigned long long h = dedup_key(P.hash[c]);
+        unsigned long long slot = h % size;
+        for (;;) {   // the table is twice the locus: a free or matching slot always exists
+            const unsigned long long prev = atomicCAS(&P.tab_key[2 * lo + slot], kDedupEmpty, h);
+            if (prev == kDedupEmpty || prev == h) { atomicMin(&P.tab_val[2 * lo + slot], (int)(c - lo)); break; }
+            slot = (slot + 1 == size) ? 0 : slot + 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dedup_resolve_kernel(DedupParams P) {
+    const int locus = P.chunk_locus[blockIdx.x];
+    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+    const int64_t base = lo + (int64_t)P.chunk_index[blockIdx.x] * 1024;
+    const bool on = P.on[locus] != 0;
+    const unsigned long long size = 2ull * (unsigned long long)(hi - lo);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t c = base + j * 256 + threadIdx.x;
+        if (c >= hi) continue;
+        int32_t rep = -1;
+        if (on && P.flag[c] == TPHIP_FLAG_OK) {
+            const unsigned long long h = dedup_key(P.hash[c]);
+            unsigned long long slot = h % size;
+            while (P.tab_key[2 * lo + slot] != h) slot = (slot + 1 == size) ? 0 : slot + 1;   // inserted by dedup_insert_kernel
+            const int64_t r = lo + P.tab_val[2 * lo + slot];
+            if (r != c) {
+                bool same = true;
+                for (int w = 0; w < P.nwords; ++w)
+                    same &= P.packed[(int64_t)w * P.ncols_total + c] == P.packed[(int64_t)w * P.ncols_total + r];
+                if (same) { rep = (int32_t)r; P.flag[c] = kFlagDuplicate; }
+            }
+        }
+        P.dup_of[c] = rep;
+    }
+}
+
+__global__ __launch_bounds__(256) void dedup_scatter_kernel(DedupParams P) {
+    const int locus = P.chunk_locus[blockIdx.x];
+    if (!P.on[locus]) return;
+    const int64_t lo = P.locus_offsets[locus], hi = P.locus_offsets[locus + 1];
+    const int64_t base = lo + (int64_t)P.chunk_index[blockIdx.x] * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t c = base + j * 256 + threadIdx.x;
+        if (c >= hi) continue;
+        const int32_t r = P.dup_of[c];
+        if (r < 0) continue;
+        P.rate[c] = P.rate[r]; P.subst[c] = P.subst[r]; P.lnl[c] = P.lnl[r]; P.flag[c] = P.flag[r];
+    }
 }
 
 }  // namespace tphip

@@ -43,6 +43,9 @@ struct ClassifyParams {
     int32_t nops;                 // drives the parsimony pass that seeds the optimiser (ColumnScan::fitch_*)
     uint32_t* packed;             // [ceil(ntaxa/8)][ncols_total] out: 8 four-bit masks per word, program tip order
     const int32_t* tip_taxon;     // [ntaxa] alignment row of the k-th tip of the program
+    int32_t start_rule;           // TPHIP_START_*: parsimony rate, or HyPhy's siteRate = 1 (bf:1050)
+    uint64_t* hash;               // [ncols_total] out (may be null): hash of the column's packed words, for the
+                                  // per-pattern de-duplication of the site-rate stage (pattern_kernels.hpp)
 };
 
 // Scalar loads of wave-uniform table entries.  classify_kernel also stores, so through plain pointers the compiler
@@ -79,6 +82,7 @@ struct ColumnScan4 {
     uint32_t uni4 = 0, set4 = k0f;
     uint32_t res8 = 0, inf8 = 0, chg8 = 0;            // byte counters since the last flush
     uint32_t word[4] = {0, 0, 0, 0};
+    uint64_t hsh[4] = {0x243F6A8885A308D3ull, 0x243F6A8885A308D3ull, 0x243F6A8885A308D3ull, 0x243F6A8885A308D3ull};
     int resolved[4] = {0, 0, 0, 0}, informative[4] = {0, 0, 0, 0};
     unsigned changes[4] = {0, 0, 0, 0};
     unsigned long long stk[4] = {0, 0, 0, 0};
@@ -176,7 +180,8 @@ __device__ __forceinline__ void classify_finish(const ClassifyParams& P, const L
         P.subst[col] = r * P.chrono_length;
         P.lnl[col] = log(L);
     } else {
-        P.rate[col] = start_log_rate(P, M, c);   // u0 for site_rate_kernel, which overwrites it with the answer
+        // u0 for site_rate_kernel, which overwrites it with the answer
+        P.rate[col] = (P.start_rule == TPHIP_START_REFERENCE) ? 0.0 : start_log_rate(P, M, c);
     }
 }
 
@@ -237,6 +242,13 @@ __global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (j < n) P.packed[(int64_t)(k >> 3) * P.ncols_total + c0 + j] = c.word[j];
             }
+            if (P.hash) {   // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t h = (c.hsh[j] ^ c.word[j]) * 0x9E3779B97F4A7C15ull;
+                    c.hsh[j] = h ^ (h >> 29);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) c.word[j] = 0;
         }
@@ -246,6 +258,10 @@ __global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
     uint8_t f[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (j < n) classify_finish(P, M, c0 + j, c.column(j), f[j]);
+    if (P.hash) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < n) P.hash[c0 + j] = c.hsh[j] ^ (c.hsh[j] >> 32);
+    }
     if (fast) {
         *reinterpret_cast<int4*>(P.nres + c0) = make_int4(c.informative[0], c.informative[1], c.informative[2], c.informative[3]);
         *reinterpret_cast<uint32_t*>(P.flag + c0) = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
@@ -313,7 +329,10 @@ struct PiParams {
 // by parity instead of by the discarded part) -- the rate would then differ by 1e-4 from what the .rates file says.
 // The FMA recovers the discarded part exactly (r * scale = p + e), and only a half-integer p needs it: otherwise p is
 // at least one ulp away from the half and |e| <= ulp/2 cannot carry it across.
+// (Contraction must stay off here: fused into fma(r, scale, -n), "p - n" would be the exact product minus n, never
+// exactly 0.5 on a false tie, and the correction below would never fire.)
 __host__ __device__ __forceinline__ double round_like_printf(double r, double scale) {
+#pragma clang fp contract(off)
     const double p = r * scale;
     const double e = fma(r, scale, -p);
     double n = rint(p);

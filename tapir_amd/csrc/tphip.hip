@@ -79,7 +79,7 @@ struct tphip_plan {
     int32_t device = 0;
     int32_t ntaxa = 0;
     int64_t nloci = 0, ncols = 0;
-    int32_t T = 0, n_t = 0, n_i = 0, integ_mode = 0, threshold = 0, round_decimals = -1;
+    int32_t T = 0, n_t = 0, n_i = 0, integ_mode = 0, threshold = 0, round_decimals = -1, start_rule = 0;
     double correction = 1.0;
     TreeProgram prog;
     std::vector<int64_t> h_offsets;
@@ -116,6 +116,8 @@ struct tphip_plan {
     DevBuf<unsigned long long> d_evals;
     // workspace layout (bytes)
     size_t ws_work_cols = 0, ws_work_count = 0, ws_work_prefix = 0, ws_slice_prefix = 0, ws_partial = 0, ws_packed = 0, ws_total = 0;
+    size_t ws_hash = 0, ws_dup_of = 0, ws_tab_key = 0, ws_tab_val = 0, ws_dedup_on = 0;   // site-pattern de-duplication
+    int32_t dedup_mode = DEDUP_AUTO;
     int32_t num_cus = 256;
     int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
     int32_t site_persistent = 1;
@@ -176,6 +178,10 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     if (!(d->correction > 0.0)) return fail(TPHIP_ERR_INVALID, "correction must be > 0");
     if (d->integ_mode != TPHIP_INTEG_QUADPACK && d->integ_mode != TPHIP_INTEG_CLOSED)
         return fail(TPHIP_ERR_INVALID, "unknown integ_mode");
+    if (d->start_rule != TPHIP_START_PARSIMONY && d->start_rule != TPHIP_START_REFERENCE)
+        return fail(TPHIP_ERR_INVALID, "unknown start_rule");
+    if (d->pattern_dedup != TPHIP_DEDUP_AUTO && d->pattern_dedup != TPHIP_DEDUP_OFF && d->pattern_dedup != TPHIP_DEDUP_ON)
+        return fail(TPHIP_ERR_INVALID, "unknown pattern_dedup");
     for (int i = 0; i < d->n_t; ++i)
         if (d->times[i] < 0 || d->times[i] >= d->T)  // numpy would raise IndexError (tapir/compute.py:78)
             return fail(TPHIP_ERR_INVALID, "a --times value is outside 0..T-1 (index out of bounds for the net PI vector)");
@@ -215,6 +221,8 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->device = d->device; p->ntaxa = d->ntaxa; p->nloci = d->nloci; p->ncols = ncols;
     p->T = d->T; p->n_t = d->n_t; p->n_i = d->n_i; p->integ_mode = d->integ_mode;
     p->threshold = d->threshold; p->round_decimals = d->round_decimals; p->correction = d->correction;
+    p->start_rule = d->start_rule;
+    p->dedup_mode = d->pattern_dedup;
     p->ncat = cat.empty() ? 0 : d->ncat;
     std::string terr = build_tree_program(d->ntaxa, d->nnodes, d->parent, d->branch_len, d->leaf_taxon, &p->prog);
     if (!terr.empty()) { delete p; return fail(TPHIP_ERR_INVALID, "tree: " + terr); }
@@ -386,6 +394,16 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->ws_slice_prefix = off; off = align_up(off + sizeof(int64_t) * ((size_t)d->nloci + 1), 256);
     p->ws_partial = off; off = align_up(off + sizeof(double) * (size_t)p->n_pi_chunks * (size_t)(d->T + 2 * d->n_i), 256);
     p->ws_packed = off; off = align_up(off + sizeof(uint32_t) * (size_t)p->nwords * (size_t)ncols, 256);
+    if (const char* e9 = getenv("TPHIP_DEDUP")) {   // test/tuning knob: 0 = never, 1 = always, anything else = automatic
+        p->dedup_mode = (e9[0] == '0') ? DEDUP_OFF : (e9[0] == '1') ? DEDUP_ON : DEDUP_AUTO;
+    }
+    if (p->dedup_mode != DEDUP_OFF) {
+        p->ws_hash = off; off = align_up(off + sizeof(uint64_t) * (size_t)ncols, 256);
+        p->ws_dup_of = off; off = align_up(off + sizeof(int32_t) * (size_t)ncols, 256);
+        p->ws_tab_key = off; off = align_up(off + sizeof(unsigned long long) * 2 * (size_t)ncols, 256);
+        p->ws_tab_val = off; off = align_up(off + sizeof(int32_t) * 2 * (size_t)ncols, 256);
+        p->ws_dedup_on = off; off = align_up(off + sizeof(int32_t) * (size_t)d->nloci, 256);
+    }
     p->ws_total = off + 256;
     *out = p;
     return TPHIP_OK;
@@ -489,8 +507,25 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     C.ops = p->d_ops.p; C.nops = (int32_t)p->prog.ops.size();
     C.packed = (uint32_t*)((char*)ws + p->ws_packed);
     C.tip_taxon = p->d_tip_taxon.p;
+    C.start_rule = p->start_rule;
+    const bool dedup = p->dedup_mode != DEDUP_OFF && p->n_pi_chunks > 0;
+    C.hash = dedup ? (uint64_t*)((char*)ws + p->ws_hash) : nullptr;
+    DedupParams D;
+    if (dedup) {
+        D.locus_offsets = p->d_offsets.p; D.chunk_locus = p->d_pi_chunk_locus.p; D.chunk_index = p->d_pi_chunk_index.p;
+        D.hash = C.hash; D.packed = C.packed; D.nwords = p->nwords; D.ncols_total = p->ncols; D.flag = d_flag;
+        D.dup_of = (int32_t*)((char*)ws + p->ws_dup_of);
+        D.tab_key = (unsigned long long*)((char*)ws + p->ws_tab_key); D.tab_val = (int32_t*)((char*)ws + p->ws_tab_val);
+        D.on = (int32_t*)((char*)ws + p->ws_dedup_on); D.mode = p->dedup_mode;
+        D.rate = d_rate; D.subst = d_subst; D.lnl = d_lnl;
+    }
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
+        if (dedup) {   // one rate per unique site pattern (bf:1033-1044); loci that hardly repeat a column skip it
+            dedup_estimate_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(D);
+            dedup_insert_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
+            dedup_resolve_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
+        }
         if (p->max_locus_cols > 2048) compact_kernel<1024><<<dim3((unsigned)p->nloci), dim3(1024), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
         else compact_kernel<256><<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
         scan_counts_kernel<<<dim3(1), dim3(1024), 0, st>>>(work_count, p->nloci, p->site_chunk_cols, (int64_t*)((char*)ws + p->ws_work_prefix),
@@ -528,6 +563,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
         else site_rate_kernel<kStreamWords><<<grid, block, lds, st>>>(S);   // more than 64 tips
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));
+    if (dedup) dedup_scatter_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
     HIP_TRY(hipGetLastError());
     return TPHIP_OK;
 }

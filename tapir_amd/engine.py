@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtphip.so")
 
 FLAG_OK, FLAG_FLAT, FLAG_SATURATED, FLAG_ZERO, FLAG_MAXIT = 0, 1, 2, 3, 4
+START_PARSIMONY, START_REFERENCE = 0, 1
+DEDUP_AUTO, DEDUP_OFF, DEDUP_ON = 0, 1, 2
 INTEG_QUADPACK, INTEG_CLOSED = 0, 1
 
 _vp = ctypes.c_void_p
@@ -29,7 +31,8 @@ class PlanDesc(ctypes.Structure):
                 ("leaf_taxon", _vp), ("nloci", _i64), ("locus_offsets", _vp), ("pi", _vp), ("exch", _vp),
                 ("T", _i32), ("times", _vp), ("n_t", _i32), ("intervals", _vp), ("n_i", _i32),
                 ("integ_mode", _i32), ("correction", _f64), ("threshold", _i32), ("round_decimals", _i32),
-                ("ncat", _i32), ("cat_rate", _vp), ("cat_weight", _vp)]
+                ("ncat", _i32), ("cat_rate", _vp), ("cat_weight", _vp), ("start_rule", _i32),
+                ("pattern_dedup", _i32)]
 
 
 # every symbol include/tphip.h declares: (name, restype, argtypes)
@@ -151,7 +154,7 @@ class Plan:
 
     def __init__(self, ntaxa, parent, branch_len, leaf_taxon, locus_offsets, pi, exch, T, times, intervals,
                  correction=1.0, threshold=3, round_decimals=4, integ_mode=INTEG_QUADPACK, device=0, cat_rates=None,
-                 cat_weights=None):
+                 cat_weights=None, start_rule=START_PARSIMONY, pattern_dedup=DEDUP_AUTO):
         lib = load()
         self._lib = lib
         self._h = _vp()
@@ -178,7 +181,8 @@ class Plan:
                      n_i=k["iv"].size // 2, integ_mode=integ_mode, correction=float(correction),
                      threshold=int(threshold), round_decimals=int(round_decimals),
                      ncat=ncat if ncat > 1 else 0, cat_rate=k["cr"].ctypes.data if ncat > 1 else None,
-                     cat_weight=k["cw"].ctypes.data if ncat > 1 else None)
+                     cat_weight=k["cw"].ctypes.data if ncat > 1 else None, start_rule=int(start_rule),
+                     pattern_dedup=int(pattern_dedup))
         _check(lib.tphip_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
         self.device = device
         self.ntaxa = ntaxa

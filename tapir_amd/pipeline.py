@@ -173,7 +173,7 @@ def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, bl
 
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
                    exch, pi=None, subsets=None, output_dir=None, device=0, integ_mode=0, round_decimals=4,
-                   engine_mod=None, progress=None, pool=None, cat_rates=None, cat_weights=None):
+                   engine_mod=None, progress=None, pool=None, cat_rates=None, cat_weights=None, start_rule=0):
     """Site rates + PI for a list of NEXUS alignments.  Returns a list of worker()-shaped tuples
     (alignment, rates, mean_rate, None, pi_net, pi_times, pi_epochs) in the order of `alignments`.
 
@@ -197,6 +197,8 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     if exch.ndim == 1:
         exch = np.tile(exch, (L, 1))
     extra = {} if cat_rates is None or len(cat_rates) <= 1 else dict(cat_rates=cat_rates, cat_weights=cat_weights)
+    if start_rule:   # every column starts at siteRate = 1 as in HyPhy (bf:1050) instead of at its parsimony rate
+        extra["start_rule"] = int(start_rule)
     plan = eng.Plan(len(leaf_names), parent, blen, leaf, offsets, pi, exch, T, times, intervals,
                     correction=correction, threshold=threshold, round_decimals=round_decimals,
                     integ_mode=integ_mode, device=device, **extra)

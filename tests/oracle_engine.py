@@ -30,8 +30,10 @@ def compress_columns(states, locus_offsets, device=0, want_map=True):
 
 class Plan:
     def __init__(self, ntaxa, parent, branch_len, leaf_taxon, locus_offsets, pi, exch, T, times, intervals,
-                 correction=1.0, threshold=3, round_decimals=4, integ_mode=0, device=0, cat_rates=None, cat_weights=None):
+                 correction=1.0, threshold=3, round_decimals=4, integ_mode=0, device=0, cat_rates=None, cat_weights=None,
+                 start_rule=0):
         self.cat_rates, self.cat_weights = cat_rates, cat_weights
+        self.start_mode = 2 if start_rule else 0   # the engine's start_rule = 1 is the oracle's start_mode 2
         self.ntaxa = ntaxa
         self.parent = np.asarray(parent, np.int32)
         self.blen = np.asarray(branch_len, np.float64)
@@ -89,7 +91,8 @@ class Plan:
             sl = slice(self.off[l], self.off[l + 1])
             if sl.stop == sl.start:
                 continue
-            r = orc.site_rates(states[:, sl], self.parent, self.blen, self.leaf, self.pi[l] / self.pi[l].sum(), self.exch[l], self.cat_rates, self.cat_weights)
+            r = orc.site_rates(states[:, sl], self.parent, self.blen, self.leaf, self.pi[l] / self.pi[l].sum(), self.exch[l], self.cat_rates, self.cat_weights,
+                               start_mode=self.start_mode)
             for k in out:
                 out[k][sl] = r[k]
         return out
@@ -97,8 +100,7 @@ class Plan:
     def pi_tables(self, rates, nres=None):
         rates = np.asarray(rates, np.float64).copy()
         if self.round_decimals >= 0:
-            s = 10.0 ** self.round_decimals
-            rates = np.round(rates * s) / s
+            rates = orc.round_dp(rates, self.round_decimals)
         rates = rates / self.correction
         if nres is not None:
             rates[np.asarray(nres) < self.threshold] = np.nan

@@ -324,6 +324,161 @@ def test_four_decimal_round_trip_matches_printf_on_ties(chr1_918):
     raw.close()
 
 
+def test_reference_start_rule(chr1_918, oracle):
+    """tphip_plan_desc.start_rule = TPHIP_START_REFERENCE: every column starts at siteRate = 1 (models_and_rates.bf:1050).
+      * against the oracle running the same optimiser from the same start (start_mode 2): flags exact, rates 1e-6;
+      * the bundled locus: default start, reference start and the oracle's independent plain-Newton-from-1 restatement
+        (start_mode 1) agree on EVERY column -- the count of differing columns is asserted to be 0;
+      * synthetic samples: the product's DEFAULT (parsimony start) against the reference-faithful restatement: columns
+        that end on a different local optimum are counted (they are multimodal columns; DESIGN.md section 5 quotes the
+        large-sample frequencies) and bounded."""
+    engine = _engine()
+    from tapir_amd import synth
+    c = chr1_918
+    n = c["states"].shape[1]
+    mk = lambda rule: engine.Plan(5, c["parent"], c["blen"], c["leaf"], [0, n], [c["pi"]], [c["exch"]], 174, [10], [[0, 10]],  # noqa: E731
+                                  correction=c["factor"], start_rule=rule)
+    p0, p1 = mk(engine.START_PARSIMONY), mk(engine.START_REFERENCE)
+    g0, g1 = p0.site_rates(c["states"]), p1.site_rates(c["states"])
+    p0.close()
+    p1.close()
+    plain = oracle.site_rates(c["states"], c["parent"], c["blen"], c["leaf"], c["pi"], c["exch"], start_mode=1)
+    same = oracle.site_rates(c["states"], c["parent"], c["blen"], c["leaf"], c["pi"], c["exch"], start_mode=2)
+    assert np.array_equal(g1["flag"], same["flag"]) and np.array_equal(g0["flag"], plain["flag"]) and np.array_equal(g1["flag"], plain["flag"])
+    ok = plain["flag"] == 0
+    for g in (g0, g1):
+        assert (np.abs(g["rate"][ok] - plain["rate"][ok]) > 1e-6 * plain["rate"][ok]).sum() == 0
+        assert np.abs(g["lnl"] - plain["lnl"]).max() < 1e-9
+    report = []
+    for name, nloci, ncols, ntaxa, seed, kw, bound in [("C2 shape", 100, 500, 16, 20261005, {}, 3e-4),
+                                                       ("C3 shape", 2, 10000, 64, 20261006, {}, 1e-4),
+                                                       ("5 noisy taxa", 40, 1000, 5, 4242, dict(rate_mean=0.02, gap_frac=0.15), 4e-3)]:
+        d = synth.simulate(nloci, ncols, ntaxa, seed, **kw)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        st = d["states"].numpy()
+        args = (ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"], [10], [[5, 15]])
+        pa, pb = engine.Plan(*args, correction=pin["correction"]), engine.Plan(*args, correction=pin["correction"], start_rule=1)
+        ga, gb = pa.site_rates(st), pb.site_rates(st)
+        kappa = pb.models()[3]
+        pa.close()
+        pb.close()
+        differ = 0
+        for l in range(nloci):
+            sl = slice(l * ncols, (l + 1) * ncols)
+            o2 = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l], start_mode=2)
+            assert np.array_equal(gb["flag"][sl], o2["flag"])
+            _assert_rates_match(oracle, gb, o2, sl, st[:, sl], pin, d["pi"][l], d["exch"][l], kappa[l])
+            o1 = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l], start_mode=1)
+            both = (ga["flag"][sl] == 0) & (o1["flag"] == 0)
+            rel = np.abs(ga["rate"][sl][both] - o1["rate"][both]) / o1["rate"][both]
+            differ += int((rel > 1e-2).sum()) + int((ga["flag"][sl] != o1["flag"]).sum())
+            # the same local optimum is located to the parity tolerance (nearly flat columns excepted: |f''| < 1e-7,
+            # they are compared through log L)
+            near = rel <= 1e-2
+            loose = rel[near] >= 1e-6
+            assert np.abs(ga["lnl"][sl][both][near][loose] - o1["lnl"][both][near][loose]).max(initial=0.0) < 1e-11
+        report.append((name, nloci * ncols, differ))
+        assert differ <= bound * nloci * ncols, (name, differ)
+    print("columns on another local optimum than the start-at-1 restatement (default start):", report)
+
+
+def test_stage2_pattern_dedup(chr1_918, monkeypatch):
+    """HyPhy fits one rate per unique column pattern of a locus (models_and_rates.bf:1033-1044).  The engine does the
+    same when a locus repeats columns (tphip_plan_desc.pattern_dedup; pattern_kernels.hpp): outputs must be bit-identical
+    with de-duplication off, forced on and automatic, on
+      * bootstrap resamples of the reference's bundled locus (2000 columns drawn from its 226: at most 57 patterns),
+      * resamples of 64- and 130-taxon synthetic loci mixed with loci that repeat nothing (ragged lengths, an empty locus);
+    the optimiser must run on unique patterns only (evaluation counts), the automatic mode must switch on for the
+    resampled loci and stay off for the synthetic batch with random gaps, and the dominant kernel must get faster."""
+    engine = _engine()
+    import torch
+    from tapir_amd import synth
+    monkeypatch.delenv("TPHIP_DEDUP", raising=False)
+    rng = np.random.default_rng(8)
+    c = chr1_918
+    L, S = 12, 2000
+    st = np.concatenate([c["states"][:, rng.integers(0, 226, S)] for _ in range(L)], axis=1)
+    off = np.arange(L + 1) * S
+    runs = {}
+    for mode in (engine.DEDUP_OFF, engine.DEDUP_ON, engine.DEDUP_AUTO):
+        plan = engine.Plan(5, c["parent"], c["blen"], c["leaf"], off, np.tile(c["pi"], (L, 1)), np.tile(c["exch"], (L, 1)), 174,
+                           [10, 20], [[0, 10], [20, 100]], correction=c["factor"], pattern_dedup=mode)
+        runs[mode] = (plan.run_fused(st), plan.last_eval_count())
+        plan.close()
+    base, ev_off = runs[engine.DEDUP_OFF]
+    for mode in (engine.DEDUP_ON, engine.DEDUP_AUTO):
+        got, ev = runs[mode]
+        for k in base:
+            assert np.array_equal(got[k], base[k], equal_nan=True), (mode, k)
+        assert ev < 0.2 * ev_off, (mode, ev, ev_off)          # <= 57 patterns (fewer need the optimiser) of 2000 columns
+    assert runs[engine.DEDUP_ON][1] == runs[engine.DEDUP_AUTO][1]
+    # duplicates of one pattern carry one answer
+    first = {}
+    for col in range(S):
+        key = st[:, col].tobytes()
+        if key in first:
+            assert base["rate"][col] == base["rate"][first[key]] and base["lnl"][col] == base["lnl"][first[key]]
+        else:
+            first[key] = col
+    # larger trees: resampled loci next to loci that repeat nothing, ragged offsets, an empty locus
+    for ntaxa, seed in ((64, 41), (130, 42)):
+        d = synth.simulate(6, 1200, ntaxa, seed)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        s0 = d["states"].numpy().copy()
+        for l in (1, 4):   # loci 1 and 4 become bootstrap resamples of their own first 150 columns
+            s0[:, l * 1200:(l + 1) * 1200] = s0[:, l * 1200 + rng.integers(0, 150, 1200)]
+        off2 = np.array([0, 1200, 2400, 2400, 4800, 6000, 7200])   # locus 2 is empty, locus 3 twice as long
+        pi6 = d["pi"]
+        outs = {}
+        for mode in (engine.DEDUP_OFF, engine.DEDUP_ON, engine.DEDUP_AUTO):
+            plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off2, pi6, d["exch"], pin["T"], [10], [[5, 15]],
+                               correction=pin["correction"], pattern_dedup=mode)
+            outs[mode] = (plan.run_fused(s0), plan.last_eval_count())
+            plan.close()
+        for mode in (engine.DEDUP_ON, engine.DEDUP_AUTO):
+            for k in outs[engine.DEDUP_OFF][0]:
+                assert np.array_equal(outs[mode][0][k], outs[engine.DEDUP_OFF][0][k], equal_nan=True), (ntaxa, mode, k)
+        assert outs[engine.DEDUP_ON][1] < 0.8 * outs[engine.DEDUP_OFF][1]     # 2400 of 7200 columns collapse to <= 300
+        # automatic: on for the resampled loci only; the loci with random gaps hardly repeat a column
+        assert outs[engine.DEDUP_ON][1] <= outs[engine.DEDUP_AUTO][1] < 0.85 * outs[engine.DEDUP_OFF][1]
+    # synthetic batch without repeats: automatic mode leaves it alone (same evaluations as off)
+    d = synth.simulate(4, 3000, 64, 43)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    ev = {}
+    for mode in (engine.DEDUP_OFF, engine.DEDUP_AUTO):
+        plan = engine.Plan(64, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"], [10],
+                           [[5, 15]], correction=pin["correction"], pattern_dedup=mode)
+        plan.run_fused(d["states"].numpy())
+        ev[mode] = plan.last_eval_count()
+        plan.close()
+    assert ev[engine.DEDUP_AUTO] > 0.97 * ev[engine.DEDUP_OFF]
+    # kernel time: 20 loci x 20 000 columns resampled from 300 columns each, 64 taxa
+    d = synth.simulate(20, 300, 64, 44)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    src = d["states"].numpy()
+    big = np.concatenate([src[:, l * 300 + rng.integers(0, 300, 20000)] for l in range(20)], axis=1)
+    t_big = torch.from_numpy(big).cuda()
+    ms = {}
+    for mode in (engine.DEDUP_OFF, engine.DEDUP_AUTO):
+        plan = engine.Plan(64, pin["parent"], pin["blen"], pin["leaf"], np.arange(21) * 20000, d["pi"], d["exch"], pin["T"], [10],
+                           [[5, 15]], correction=pin["correction"], pattern_dedup=mode)
+        n = plan.ncols
+        o = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
+        fl, nr = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda")
+        tb = torch.empty((20, plan.width), dtype=torch.float64, device="cuda")
+        ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda")
+        plan.profile_enable(True)
+        for _ in range(3):
+            plan.run_dev(t_big, o[0], o[1], o[2], fl, nr, tb, ws, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        site_ms, _, launches = plan.profile_read()
+        ms[mode] = (site_ms / launches, o[0].clone(), tb.clone())
+        plan.close()
+    assert torch.equal(ms[engine.DEDUP_OFF][1], ms[engine.DEDUP_AUTO][1]) and torch.equal(ms[engine.DEDUP_OFF][2], ms[engine.DEDUP_AUTO][2])
+    print("site_rate_kernel ms, 400 000 resampled columns: off %.3f, auto %.3f" % (ms[engine.DEDUP_OFF][0], ms[engine.DEDUP_AUTO][0]))
+    assert ms[engine.DEDUP_AUTO][0] < 0.5 * ms[engine.DEDUP_OFF][0]
+
+
 def test_engine_before_torch_in_one_process():
     """Round 1 saw torch report "No HIP GPUs are available" when it initialised after libtphip in the same process: the
     library had bound /opt/rocm's HIP runtime, torch then mapped its bundled copy, and the second ROCr in a process

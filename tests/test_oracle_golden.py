@@ -116,6 +116,57 @@ def test_site_rates_known_answer_file(oracle, golden_dir):
     assert (r["rate"][ok] == 0).sum() == 131
 
 
+@pytest.mark.parametrize("start_mode", [1, 2])
+def test_reference_start_modes_on_the_known_answer_file(oracle, golden_dir, start_mode):
+    """The oracle's reference-faithful mode (start_mode 1: every column starts at siteRate = 1 as in
+    models_and_rates.bf:1050, plain safeguarded Newton to 1e-12, none of the product's accelerations) and the product's
+    optimiser started at 1 (start_mode 2) against the PhyDesign known-answer file: the same 180/180 log-likelihoods and
+    177/177 rates as the default mode, and NO column of the bundled locus on which the three modes disagree."""
+    kat = json.load(open(os.path.join(golden_dir, "chr1_918_phydesign_rates.json")))
+    names, rows = oracle.read_nexus_matrix(os.path.join(golden_dir, "chr1_918.nex"))
+    st = oracle.encode_rows(rows)
+    depth, factor, root = oracle.correct_branch_lengths_values(open(os.path.join(golden_dir, "Euteleost.tree")).read())
+    parent, blen, leaf = oracle.tree_arrays(root, names)
+    pi = np.array(kat["freqs_ACGT"])
+    exch = np.array([kat[k] for k in ("AC", "AG", "AT", "CG", "CT", "GT")])
+    r = oracle.site_rates(st, parent, blen, leaf, pi, exch, start_mode=start_mode)
+    inf = r["nres"] >= 3
+    assert inf.sum() == 180
+    assert np.abs(r["lnl"] - np.array(kat["ll"]))[inf].max() < 5.1e-5
+    ok = inf & ((r["flag"] == 0) | (r["flag"] == 3))
+    assert ok.sum() == 177
+    assert np.abs(r["rate"] - np.array(kat["rate"]))[ok].max() < 5.1e-5
+    d = oracle.site_rates(st, parent, blen, leaf, pi, exch)          # default: parsimony start, accelerated exits
+    assert np.array_equal(d["flag"], r["flag"])
+    both = (d["flag"] == 0)
+    assert (np.abs(d["rate"][both] - r["rate"][both]) > 1e-6 * r["rate"][both]).sum() == 0
+    assert np.abs(d["lnl"] - r["lnl"]).max() < 1e-9
+
+
+def test_start_modes_agree_on_unimodal_columns_and_differ_rarely(oracle):
+    """Parsimony start + accelerated exits (mode 0) against the reference-faithful mode (1) on seeded synthetic columns:
+    wherever both end on the same local optimum they agree far below 1e-6; the columns on which they do not are
+    multimodal ones (two local maxima more than a log-unit apart), a few per 10^5 at 16 taxa (tools/start_mode_census.py
+    has the large-sample figures quoted in DESIGN.md)."""
+    from tapir_amd import synth
+    d = synth.simulate(40, 500, 16, 20261005)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    n = differ = 0
+    for l in range(40):
+        sl = slice(l * 500, (l + 1) * 500)
+        a = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l])
+        b = oracle.site_rates(st[:, sl], pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l], start_mode=1)
+        both = (a["flag"] == 0) & (b["flag"] == 0)
+        rel = np.abs(a["rate"][both] - b["rate"][both]) / b["rate"][both]
+        same = rel < 1e-2                      # the same local optimum ...
+        assert rel[same].max() < 1e-6          # ... located to the parity tolerance by both
+        differ += int((~same).sum()) + int((a["flag"] != b["flag"]).sum())
+        n += 500
+        assert b["nevals"] > a["nevals"]       # the faithful mode pays for it
+    assert differ <= 5, differ                 # 20 000 columns: expect ~1
+
+
 def test_informative_mask_goldens(oracle, golden_dir):
     """chr1_918-test-cutoff-values.npy (threshold 3) and the 4-column toy alignment of
     test_compute.py:99-103 (expected [nan, nan, 1, 1])."""
