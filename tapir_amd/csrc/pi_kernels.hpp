@@ -43,7 +43,7 @@ struct ClassifyParams {
     int32_t nops;                 // drives the parsimony pass that seeds the optimiser (ColumnScan::fitch_*)
     uint32_t* packed;             // [ceil(ntaxa/8)][ncols_total] out: 8 four-bit masks per word, program tip order
     const int32_t* tip_taxon;     // [ntaxa] alignment row of the k-th tip of the program
-    int32_t start_rule;           // TPHIP_START_*: parsimony rate, or HyPhy's siteRate = 1 (bf:1050)
+    double start_scale;           // 1: start at the parsimony rate; 0: at HyPhy's siteRate = 1 (bf:1050), TPHIP_START_*
     uint64_t* hash;               // [ncols_total] out (may be null): hash of the column's packed words, for the
                                   // per-pattern de-duplication of the site-rate stage (pattern_kernels.hpp)
 };
@@ -180,8 +180,9 @@ __device__ __forceinline__ void classify_finish(const ClassifyParams& P, const L
         P.subst[col] = r * P.chrono_length;
         P.lnl[col] = log(L);
     } else {
-        // u0 for site_rate_kernel, which overwrites it with the answer
-        P.rate[col] = (P.start_rule == TPHIP_START_REFERENCE) ? 0.0 : start_log_rate(P, M, c);
+        // u0 for site_rate_kernel, which overwrites it with the answer: the parsimony start, or u = log 1 = 0 when the
+        // plan asks for HyPhy's start value (start_scale = 0; a multiplication, not a branch: + 0.0 turns -0.0 into 0.0)
+        P.rate[col] = start_log_rate(P, M, c) * P.start_scale + 0.0;
     }
 }
 

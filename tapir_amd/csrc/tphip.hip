@@ -11,11 +11,12 @@
 #include <vector>
 
 #include "gtr_model.hpp"
+#include "gtr_setup_kernel.hpp"
 #include "locus_lik_kernel.hpp"
 #include "pattern_kernels.hpp"
 #include <hipcub/hipcub.hpp>
 #include "pi_kernels.hpp"
-#include "site_rate_kernel.hpp"
+#include "site_rate_params.hpp"
 #include "tphip.h"
 #include "tree_program.hpp"
 
@@ -323,11 +324,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         hipDeviceProp_t prop;
         int per_cu = 0;
         if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) { tphip_plan_destroy(p); return fail(TPHIP_ERR_HIP, "hipGetDeviceProperties failed"); }
-        auto occ = [&](auto kern) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kSiteBlock, lds_bytes); };
-        hipError_t oe;
-        if (p->nwords <= 2) oe = occ(site_rate_kernel<2>);
-        else if (p->nwords <= 8) oe = occ(site_rate_kernel<8>);
-        else oe = occ(site_rate_kernel<kStreamWords>);
+        const hipError_t oe = site_rate_kernel_occupancy(p->nwords <= 2 ? 2 : p->nwords <= 8 ? 8 : kStreamWords, lds_bytes, &per_cu);
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         p->site_waves = per_cu * prop.multiProcessorCount;
         p->num_cus = prop.multiProcessorCount;
@@ -507,7 +504,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     C.ops = p->d_ops.p; C.nops = (int32_t)p->prog.ops.size();
     C.packed = (uint32_t*)((char*)ws + p->ws_packed);
     C.tip_taxon = p->d_tip_taxon.p;
-    C.start_rule = p->start_rule;
+    C.start_scale = (p->start_rule == TPHIP_START_REFERENCE) ? 0.0 : 1.0;
     const bool dedup = p->dedup_mode != DEDUP_OFF && p->n_pi_chunks > 0;
     C.hash = dedup ? (uint64_t*)((char*)ws + p->ws_hash) : nullptr;
     DedupParams D;
@@ -528,8 +525,8 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
         }
         if (p->max_locus_cols > 2048) compact_kernel<1024><<<dim3((unsigned)p->nloci), dim3(1024), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
         else compact_kernel<256><<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(d_flag, p->d_offsets.p, work_cols, work_count);
-        scan_counts_kernel<<<dim3(1), dim3(1024), 0, st>>>(work_count, p->nloci, p->site_chunk_cols, (int64_t*)((char*)ws + p->ws_work_prefix),
-                                                           (int64_t*)((char*)ws + p->ws_slice_prefix));
+        HIP_TRY(launch_scan_counts_kernel(st, work_count, p->nloci, p->site_chunk_cols, (int64_t*)((char*)ws + p->ws_work_prefix),
+                                          (int64_t*)((char*)ws + p->ws_slice_prefix)));
     }
     HIP_TRY(hipMemsetAsync(p->d_evals.p, 0, sizeof(unsigned long long), st));
     SiteParams S;
@@ -550,17 +547,15 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_site_chunks > 0) {
-        const dim3 grid((unsigned)(p->site_persistent ? p->site_waves * p->site_grid_mult : p->n_site_chunks)), block(kSiteBlock);
+        const dim3 grid((unsigned)(p->site_persistent ? p->site_waves * p->site_grid_mult : p->n_site_chunks));
         // packed tip states: in registers up to 64 tips, streamed one word ahead beyond (site_rate_kernel.hpp)
         const bool byte_path = p->force_byte_path;   // test/tuning knob, resolved at plan creation
         if (!byte_path) {  // the packed path reads the stream with fused cherries (tree_program.hpp)
             S.ops = p->d_fused_ops.p;
             S.nops = (int32_t)p->prog.fused_ops.size();
         }
-        if (byte_path) site_rate_kernel<0><<<grid, block, lds, st>>>(S);
-        else if (p->nwords <= 2) site_rate_kernel<2><<<grid, block, lds, st>>>(S);
-        else if (p->nwords <= 8) site_rate_kernel<8><<<grid, block, lds, st>>>(S);
-        else site_rate_kernel<kStreamWords><<<grid, block, lds, st>>>(S);   // more than 64 tips
+        // variants: byte path; packed words in registers (<= 16 / <= 64 tips); streamed words (more than 64 tips)
+        HIP_TRY(launch_site_rate_kernel(byte_path ? 0 : p->nwords <= 2 ? 2 : p->nwords <= 8 ? 8 : kStreamWords, grid, lds, st, S));
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));
     if (dedup) dedup_scatter_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
@@ -961,8 +956,7 @@ int tphip_eval_columns_dev(tphip_plan* p, const uint8_t* d_s, const double* d_u,
     E.S.flag = nullptr; E.S.eval_counter = nullptr;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
-    if (p->n_site_chunks > 0) eval_columns_kernel<<<dim3((unsigned)p->n_site_chunks), dim3(kSiteBlock), lds, (hipStream_t)stream>>>(E);
-    HIP_TRY(hipGetLastError());
+    if (p->n_site_chunks > 0) HIP_TRY(launch_eval_columns_kernel(dim3((unsigned)p->n_site_chunks), lds, (hipStream_t)stream, E));
     return TPHIP_OK;
 }
 
