@@ -239,20 +239,22 @@ __global__ __launch_bounds__(256) void dedup_resolve_kernel(DedupParams P) {
     for (int j = 0; j < 4; ++j) {
         const int64_t c = base + j * 256 + threadIdx.x;
         if (c >= hi) continue;
-        int32_t rep = -1;
+        // (dup_of is written by plain stores on each path, not through one merged value: the hipcc of ROCm 7.2 lost the
+        //  representative in the phi of `rep = same ? r : -1` after the comparison loop -- IR right, ISA wrong)
+        P.dup_of[c] = -1;
         if (on && P.flag[c] == TPHIP_FLAG_OK) {
             const unsigned long long h = dedup_key(P.hash[c]);
             unsigned long long slot = h % size;
             while (P.tab_key[2 * lo + slot] != h) slot = (slot + 1 == size) ? 0 : slot + 1;   // inserted by dedup_insert_kernel
             const int64_t r = lo + P.tab_val[2 * lo + slot];
-            if (r != c) {
-                bool same = true;
-                for (int w = 0; w < P.nwords; ++w)
-                    same &= P.packed[(int64_t)w * P.ncols_total + c] == P.packed[(int64_t)w * P.ncols_total + r];
-                if (same) { rep = (int32_t)r; P.flag[c] = kFlagDuplicate; }
+            unsigned differ = (r == c) ? 1u : 0u;
+            for (int w = 0; w < P.nwords; ++w)
+                differ |= P.packed[(int64_t)w * P.ncols_total + c] ^ P.packed[(int64_t)w * P.ncols_total + r];
+            if (differ == 0u) {
+                P.dup_of[c] = (int32_t)r;
+                P.flag[c] = kFlagDuplicate;
             }
         }
-        P.dup_of[c] = rep;
     }
 }
 
