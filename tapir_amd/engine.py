@@ -140,7 +140,11 @@ def _ptr(a):
     if a is None:
         return None
     if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise TphipError("array passed to libtphip is not C-contiguous")
         return a.ctypes.data
+    if not a.is_contiguous():   # the library sees only the pointer: a strided tensor would be read as garbage
+        raise TphipError("tensor passed to libtphip is not contiguous")
     return a.data_ptr()
 
 

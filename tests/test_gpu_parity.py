@@ -452,30 +452,33 @@ def test_stage2_pattern_dedup(chr1_918, monkeypatch):
         ev[mode] = plan.last_eval_count()
         plan.close()
     assert ev[engine.DEDUP_AUTO] > 0.97 * ev[engine.DEDUP_OFF]
-    # kernel time: 20 loci x 20 000 columns resampled from 300 columns each, 64 taxa
-    d = synth.simulate(20, 300, 64, 44)
+    # kernel time: 40 loci x 50 000 columns resampled from 1000 columns each, 64 taxa
+    d = synth.simulate(40, 1000, 64, 44)
     pin = synth.plan_inputs(d["root"], d["names"])
     src = d["states"].numpy()
-    big = np.concatenate([src[:, l * 300 + rng.integers(0, 300, 20000)] for l in range(20)], axis=1)
-    t_big = torch.from_numpy(big).cuda()
+    big = np.concatenate([src[:, l * 1000 + rng.integers(0, 1000, 50000)] for l in range(40)], axis=1)
+    t_big = torch.from_numpy(np.ascontiguousarray(big)).cuda()   # (fancy indexing + concatenate give a Fortran-ordered array)
     ms = {}
     for mode in (engine.DEDUP_OFF, engine.DEDUP_AUTO):
-        plan = engine.Plan(64, pin["parent"], pin["blen"], pin["leaf"], np.arange(21) * 20000, d["pi"], d["exch"], pin["T"], [10],
+        plan = engine.Plan(64, pin["parent"], pin["blen"], pin["leaf"], np.arange(41) * 50000, d["pi"], d["exch"], pin["T"], [10],
                            [[5, 15]], correction=pin["correction"], pattern_dedup=mode)
         n = plan.ncols
         o = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(3)]
         fl, nr = torch.empty(n, dtype=torch.uint8, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda")
-        tb = torch.empty((20, plan.width), dtype=torch.float64, device="cuda")
+        tb = torch.empty((40, plan.width), dtype=torch.float64, device="cuda")
         ws = torch.empty(plan.workspace_bytes, dtype=torch.uint8, device="cuda")
         plan.profile_enable(True)
         for _ in range(3):
             plan.run_dev(t_big, o[0], o[1], o[2], fl, nr, tb, ws, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         site_ms, _, launches = plan.profile_read()
-        ms[mode] = (site_ms / launches, o[0].clone(), tb.clone())
+        ms[mode] = (site_ms / launches, o[0].clone(), tb.clone(), plan.last_eval_count(),
+                    torch.bincount(fl.to(torch.int64), minlength=5).cpu().numpy().tolist())
         plan.close()
     assert torch.equal(ms[engine.DEDUP_OFF][1], ms[engine.DEDUP_AUTO][1]) and torch.equal(ms[engine.DEDUP_OFF][2], ms[engine.DEDUP_AUTO][2])
-    print("site_rate_kernel ms, 400 000 resampled columns: off %.3f, auto %.3f" % (ms[engine.DEDUP_OFF][0], ms[engine.DEDUP_AUTO][0]))
+    print("site_rate_kernel, 2 000 000 resampled columns: off %.3f ms (%d evaluations), auto %.3f ms (%d evaluations); flags %s"
+          % (ms[engine.DEDUP_OFF][0], ms[engine.DEDUP_OFF][3], ms[engine.DEDUP_AUTO][0], ms[engine.DEDUP_AUTO][3], ms[engine.DEDUP_OFF][4]))
+    assert ms[engine.DEDUP_AUTO][3] < 0.05 * ms[engine.DEDUP_OFF][3]
     assert ms[engine.DEDUP_AUTO][0] < 0.5 * ms[engine.DEDUP_OFF][0]
 
 
