@@ -233,6 +233,11 @@ int tphip_last_eval_count(tphip_plan *plan, int64_t *evals);
 /* ------------------------------------------------------------------------------------------------
  * Host-pointer entry points: same stages, library does the copies (PCIe time included by construction).
  * ---------------------------------------------------------------------------------------------- */
+/* Pinned host memory for the buffers of the host-pointer calls: with it the copies are direct DMA and the per-column
+ * results travel while the PI kernels run; ordinary (pageable) memory works too, through the runtime's staged copies.
+ * NULL (and tphip_last_error) when it fails.  Free with tphip_host_free. */
+void *tphip_host_alloc(size_t bytes);
+int tphip_host_free(void *ptr);
 int tphip_site_rates(tphip_plan *plan, const uint8_t *states, double *rate, double *subst, double *lnl,
                      uint8_t *flag, int32_t *nres);
 int tphip_pi_tables(tphip_plan *plan, const double *rates, const int32_t *nres, double *tables);

@@ -27,6 +27,9 @@ from . import base, compute, db, newick, pipeline
 from . import dist as tdist
 
 
+LAST_TIMINGS = {}   # seconds per stage of the last main() call on this rank (tools/e2e_cli_timing.py)
+
+
 def get_args(argv=None):
     """Get CLI arguments and options (mirrors bin/tapir_compute.py:18-53)."""
     parser = argparse.ArgumentParser(description="""tapir:  compute the
@@ -213,6 +216,8 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
                                                cat_rates=cat_rates, cat_weights=cat_weights,
                                                start_rule=1 if args.reference_start else 0)
             tables = out["final_tables"]
+            LAST_TIMINGS.clear()
+            LAST_TIMINGS.update(out.get("timings", {}))
         else:
             pis, tables = [], np.zeros((0, W))
     else:
@@ -230,6 +235,8 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
     all_tables = _gather_rows(tables, len(files), rank, world, on_gpu)
     if rank == 0:
         # store results somewhere
+        import time
+        t_db = time.perf_counter()
         db_name = os.path.join(args.output, 'phylogenetic-informativeness.sqlite')
         sys.stdout.write("\nStoring results in {0}...".format(db_name))
         sys.stdout.flush()
@@ -244,6 +251,7 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
         print("\n")
         c.close()
         conn.close()
+        LAST_TIMINGS["sqlite"] = time.perf_counter() - t_db
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -76,7 +76,11 @@ struct Scratch {
 };
 }  // namespace
 
+struct tphip_host_buffers;
+static void free_host_buffers(struct tphip_plan* p);
+
 struct tphip_plan {
+    tphip_host_buffers* hostbuf = nullptr;   // device buffers, streams and events of the host-pointer entry points
     int32_t device = 0;
     int32_t ntaxa = 0;
     int64_t nloci = 0, ncols = 0;
@@ -154,6 +158,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
     plan->d_lik_ops.release();
     plan->d_cat.release();
+    free_host_buffers(plan);
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
@@ -519,7 +524,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
         if (dedup) {   // one rate per unique site pattern (bf:1033-1044); loci that hardly repeat a column skip it
-            dedup_estimate_kernel<<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(D);
+            dedup_estimate_kernel<<<dim3((unsigned)p->nloci), dim3(kDedupEstimateBlock), 0, st>>>(D);
             dedup_insert_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
             dedup_resolve_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
         }
@@ -835,57 +840,123 @@ int tphip_state_histogram_dev(int32_t device, const uint8_t* d_states, int64_t n
 
 // ---- host-pointer wrappers -------------------------------------------------------------------------
 
+// Host-pointer calls keep their device buffers in the plan (grown on demand, freed with the plan): a hipMalloc /
+// hipFree pair per buffer per call cost more than the kernels of a small batch.  Copies are asynchronous on a second
+// stream where the caller's memory allows it (pinned: tphip_host_alloc, or registered by the caller): the per-column
+// outputs leave the device while the PI kernels run, and rate / flag / nres leave as soon as the site-rate stage ends.
+// Pageable memory is copied by the runtime's own staged hipMemcpy (same code path, no overlap).
 namespace {
-struct HostRun {
-    tphip_plan* p;
-    uint8_t* states = nullptr; double *rate = nullptr, *subst = nullptr, *lnl = nullptr, *tables = nullptr;
-    uint8_t* flag = nullptr; int32_t* nres = nullptr; void* ws = nullptr;
-    explicit HostRun(tphip_plan* plan) : p(plan) {}
-    ~HostRun() {
-        for (void* q : {(void*)states, (void*)rate, (void*)subst, (void*)lnl, (void*)tables, (void*)flag, (void*)nres, ws})
-            if (q) (void)hipFree(q);
-    }
+struct HostBuffers {
+    uint8_t* states = nullptr; size_t states_bytes = 0;
+    char* percol = nullptr; size_t percol_bytes = 0;    // rate | subst | lnl | nres | flag, one allocation
+    double* tables = nullptr; size_t tables_bytes = 0;
+    void* ws = nullptr; size_t ws_bytes = 0;
+    hipStream_t copy_stream = nullptr, run_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_site = nullptr;
 };
+
+int grow(void** ptr, size_t& have, size_t need) {
+    if (need <= have && *ptr) return TPHIP_OK;
+    if (*ptr) { HIP_TRY(hipFree(*ptr)); *ptr = nullptr; have = 0; }
+    HIP_TRY(hipMalloc(ptr, need ? need : 1));
+    have = need;
+    return TPHIP_OK;
+}
+
+bool is_pinned(const void* q) {   // host memory the DMA engines can reach directly
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
 }  // namespace
+
+struct tphip_host_buffers : HostBuffers {};
+
+static void free_host_buffers(tphip_plan* p) {
+    HostBuffers* B = p->hostbuf;
+    if (!B) return;
+    for (void* q : {(void*)B->states, (void*)B->percol, (void*)B->tables, B->ws}) if (q) (void)hipFree(q);
+    if (B->copy_stream) (void)hipStreamDestroy(B->copy_stream);
+    if (B->run_stream) (void)hipStreamDestroy(B->run_stream);
+    if (B->ev_in) (void)hipEventDestroy(B->ev_in);
+    if (B->ev_site) (void)hipEventDestroy(B->ev_site);
+    delete B;
+    p->hostbuf = nullptr;
+}
 
 static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in, const int32_t* nres_in, double* rate,
                     double* subst, double* lnl, uint8_t* flag, int32_t* nres, double* tables, bool do_site, bool do_pi) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
     HIP_TRY(hipSetDevice(p->device));
-    HostRun R(p);
+    if (!p->hostbuf) {
+        p->hostbuf = new tphip_host_buffers();
+        HIP_TRY(hipStreamCreateWithFlags(&p->hostbuf->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p->hostbuf->run_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->hostbuf->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->hostbuf->ev_site, hipEventDisableTiming));
+    }
+    HostBuffers& B = *p->hostbuf;
     const size_t n = (size_t)p->ncols, W = (size_t)tphip_plan_table_width(p);
-    HIP_TRY(hipMalloc((void**)&R.rate, sizeof(double) * (n ? n : 1)));
-    HIP_TRY(hipMalloc((void**)&R.nres, sizeof(int32_t) * (n ? n : 1)));
-    HIP_TRY(hipMalloc(&R.ws, p->ws_total));
+    // per-column block: rate | subst | lnl (8 B each) | nres (4 B) | flag (1 B), each part 256-byte aligned
+    const size_t o_rate = 0, o_subst = align_up(8 * n, 256), o_lnl = o_subst + align_up(8 * n, 256),
+                 o_nres = o_lnl + align_up(8 * n, 256), o_flag = o_nres + align_up(4 * n, 256);
+    int rc = grow((void**)&B.percol, B.percol_bytes, o_flag + align_up(n, 256));
+    if (rc) return rc;
+    rc = grow(&B.ws, B.ws_bytes, p->ws_total);
+    if (rc) return rc;
+    double* d_rate = (double*)(B.percol + o_rate);
+    double* d_subst = (double*)(B.percol + o_subst);
+    double* d_lnl = (double*)(B.percol + o_lnl);
+    int32_t* d_nres = (int32_t*)(B.percol + o_nres);
+    uint8_t* d_flag = (uint8_t*)(B.percol + o_flag);
+    hipStream_t cs = B.copy_stream, rs = B.run_stream;
     if (do_site) {
         if (!states || !rate || !subst || !lnl || !flag || !nres) return fail(TPHIP_ERR_INVALID, "null host pointer");
-        HIP_TRY(hipMalloc((void**)&R.states, n * (size_t)p->ntaxa + 1));
-        HIP_TRY(hipMalloc((void**)&R.subst, sizeof(double) * (n ? n : 1)));
-        HIP_TRY(hipMalloc((void**)&R.lnl, sizeof(double) * (n ? n : 1)));
-        HIP_TRY(hipMalloc((void**)&R.flag, n ? n : 1));
-        HIP_TRY(hipMemcpy(R.states, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice));
-        int rc = launch_site_rates(p, R.states, R.rate, R.subst, R.lnl, R.flag, R.nres, R.ws, nullptr, -1);
+        rc = grow((void**)&B.states, B.states_bytes, n * (size_t)p->ntaxa + 1);
         if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(B.states, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice, rs));
+        rc = launch_site_rates(p, B.states, d_rate, d_subst, d_lnl, d_flag, d_nres, B.ws, rs, -1);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(B.ev_site, rs));
     } else {
         if (!rates_in) return fail(TPHIP_ERR_INVALID, "null host pointer");
-        HIP_TRY(hipMemcpy(R.rate, rates_in, sizeof(double) * n, hipMemcpyHostToDevice));
-        if (nres_in) HIP_TRY(hipMemcpy(R.nres, nres_in, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(d_rate, rates_in, sizeof(double) * n, hipMemcpyHostToDevice, rs));
+        if (nres_in) HIP_TRY(hipMemcpyAsync(d_nres, nres_in, sizeof(int32_t) * n, hipMemcpyHostToDevice, rs));
     }
     if (do_pi) {
         if (!tables) return fail(TPHIP_ERR_INVALID, "null host pointer");
-        HIP_TRY(hipMalloc((void**)&R.tables, sizeof(double) * W * (size_t)p->nloci + 8));
-        int rc = launch_pi_tables(p, R.rate, (do_site || nres_in) ? R.nres : nullptr, R.tables, R.ws, nullptr, -1);
+        rc = grow((void**)&B.tables, B.tables_bytes, sizeof(double) * W * (size_t)p->nloci + 8);
+        if (rc) return rc;
+        rc = launch_pi_tables(p, d_rate, (do_site || nres_in) ? d_nres : nullptr, B.tables, B.ws, rs, -1);
         if (rc) return rc;
     }
-    HIP_TRY(hipDeviceSynchronize());
     if (do_site) {
-        HIP_TRY(hipMemcpy(rate, R.rate, sizeof(double) * n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(subst, R.subst, sizeof(double) * n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(lnl, R.lnl, sizeof(double) * n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(flag, R.flag, n, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(nres, R.nres, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        // the per-column results go home on the copy stream while the PI kernels (which only read them) run; with
+        // pageable destinations the runtime stages the copies itself and they simply run in order
+        const bool overlap = is_pinned(rate) && is_pinned(subst) && is_pinned(lnl) && is_pinned(flag) && is_pinned(nres);
+        hipStream_t os = overlap ? cs : rs;
+        if (overlap) HIP_TRY(hipStreamWaitEvent(cs, B.ev_site, 0));
+        HIP_TRY(hipMemcpyAsync(rate, d_rate, sizeof(double) * n, hipMemcpyDeviceToHost, os));
+        HIP_TRY(hipMemcpyAsync(subst, d_subst, sizeof(double) * n, hipMemcpyDeviceToHost, os));
+        HIP_TRY(hipMemcpyAsync(lnl, d_lnl, sizeof(double) * n, hipMemcpyDeviceToHost, os));
+        HIP_TRY(hipMemcpyAsync(flag, d_flag, n, hipMemcpyDeviceToHost, os));
+        HIP_TRY(hipMemcpyAsync(nres, d_nres, sizeof(int32_t) * n, hipMemcpyDeviceToHost, os));
     }
-    if (do_pi) HIP_TRY(hipMemcpy(tables, R.tables, sizeof(double) * W * (size_t)p->nloci, hipMemcpyDeviceToHost));
+    if (do_pi) HIP_TRY(hipMemcpyAsync(tables, B.tables, sizeof(double) * W * (size_t)p->nloci, hipMemcpyDeviceToHost, rs));
+    HIP_TRY(hipStreamSynchronize(rs));
+    HIP_TRY(hipStreamSynchronize(cs));
+    return TPHIP_OK;
+}
+
+void* tphip_host_alloc(size_t bytes) {
+    void* q = nullptr;
+    if (tphip_device_count() <= 0) { fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path"); return nullptr; }
+    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { fail(TPHIP_ERR_HIP, "hipHostMalloc failed"); return nullptr; }
+    return q;
+}
+
+int tphip_host_free(void* ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
     return TPHIP_OK;
 }
 

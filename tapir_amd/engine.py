@@ -61,6 +61,8 @@ SYMBOLS = [
     ("tphip_profile_enable", ctypes.c_int, [_vp, _i32]),
     ("tphip_profile_read", ctypes.c_int, [_vp, ctypes.POINTER(_f64), ctypes.POINTER(_f64), ctypes.POINTER(_i64), _i32]),
     ("tphip_last_eval_count", ctypes.c_int, [_vp, ctypes.POINTER(_i64)]),
+    ("tphip_host_alloc", _vp, [ctypes.c_size_t]),
+    ("tphip_host_free", ctypes.c_int, [_vp]),
     ("tphip_site_rates", ctypes.c_int, [_vp] * 7),
     ("tphip_pi_tables", ctypes.c_int, [_vp] * 4),
     ("tphip_run_fused", ctypes.c_int, [_vp] * 8),
@@ -146,6 +148,39 @@ def _ptr(a):
     if not a.is_contiguous():   # the library sees only the pointer: a strided tensor would be read as garbage
         raise TphipError("tensor passed to libtphip is not contiguous")
     return a.data_ptr()
+
+
+class _Pinned:
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().tphip_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in pinned host memory (tphip_host_alloc): the host-pointer calls then copy by direct DMA and overlap
+    the result copies with the PI kernels.  Falls back to ordinary memory when pinning fails."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    ptr = load().tphip_host_alloc(max(n, 1))
+    if not ptr:
+        return np.empty(shape, dtype)
+    holder = _Pinned(ptr)
+    buf = (ctypes.c_char * max(n, 1)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    _PINNED_HOLDERS[id(buf)] = holder   # keep the allocation alive as long as the ctypes buffer (= the array's base) lives
+    import weakref
+    weakref.finalize(buf, _PINNED_HOLDERS.pop, id(buf), None)
+    return arr
+
+
+_PINNED_HOLDERS = {}
 
 
 class Plan:
@@ -234,12 +269,14 @@ class Plan:
         _check(self._lib.tphip_pi_tables(self._h, rates.ctypes.data, _ptr(nres), tables.ctypes.data))
         return tables
 
-    def run_fused(self, states):
+    def run_fused(self, states, pinned=False):
+        """pinned=True: the result arrays live in pinned memory (direct DMA, copies overlapped with the PI kernels)."""
         states = _np(states, np.uint8)
         assert states.shape == (self.ntaxa, self.ncols), (states.shape, self.ntaxa, self.ncols)
         n = self.ncols
-        out = dict(rate=np.empty(n), subst=np.empty(n), lnl=np.empty(n), flag=np.empty(n, np.uint8),
-                   nres=np.empty(n, np.int32), tables=np.empty((self.nloci, self.width)))
+        new = pinned_empty if pinned else np.empty
+        out = dict(rate=new(n, np.float64), subst=new(n, np.float64), lnl=new(n, np.float64), flag=new(n, np.uint8),
+                   nres=new(n, np.int32), tables=np.empty((self.nloci, self.width)))
         _check(self._lib.tphip_run_fused(self._h, states.ctypes.data, out["rate"].ctypes.data, out["subst"].ctypes.data,
                                          out["lnl"].ctypes.data, out["flag"].ctypes.data, out["nres"].ctypes.data,
                                          out["tables"].ctypes.data))

@@ -58,10 +58,11 @@ class HostPool:
         self.close()
 
 
-def load_alignments(paths, leaf_names, pool=None):
+def load_alignments(paths, leaf_names, pool=None, alloc=None):
     """Read NEXUS alignments and flatten them: returns (states uint8 [ntaxa, ncols_total], offsets int64[L+1]).
     Rows follow `leaf_names` (the tree's leaves); an alignment must hold exactly those taxa, as HyPhy
-    requires of (siteFilter, siteTree).  pool: a HostPool parses the files in parallel (--multiprocessing)."""
+    requires of (siteFilter, siteTree).  pool: a HostPool parses the files in parallel (--multiprocessing).
+    alloc(shape, dtype): where the flattened array lives (engine.pinned_empty: the H2D copy is then direct DMA)."""
     if pool is not None and len(paths) > 1:
         parsed = pool.parse(paths)
     else:
@@ -77,8 +78,10 @@ def load_alignments(paths, leaf_names, pool=None):
         order = [names.index(n) for n in leaf_names]
         blocks.append(st[order])
         offsets.append(offsets[-1] + st.shape[1])
-    states = np.concatenate(blocks, axis=1) if blocks else np.zeros((len(leaf_names), 0), np.uint8)
-    return np.ascontiguousarray(states), np.asarray(offsets, dtype=np.int64)
+    states = (alloc or np.empty)((len(leaf_names), offsets[-1]), np.uint8)
+    for l, blk in enumerate(blocks):
+        states[:, offsets[l]:offsets[l + 1]] = blk
+    return states, np.asarray(offsets, dtype=np.int64)
 
 
 def format_rates_json(freqs, exch, site, subst, rate, ll, corrected):
@@ -184,15 +187,28 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     if eng is None:
         from . import engine as eng
     subsets = subsets or {}
-    states, offsets = load_alignments(alignments, leaf_names, pool)
+    import time
+    timings = {}          # seconds per stage of this call (out["timings"]; tools/e2e_cli_timing.py prints them)
+    t_mark = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        timings[name] = timings.get(name, 0.0) + now - t_mark[0]
+        t_mark[0] = now
+
+    pinned = getattr(eng, "pinned_empty", None)   # the real engine: I/O arrays in pinned memory
+    states, offsets = load_alignments(alignments, leaf_names, pool, alloc=pinned)
+    lap("parse_nexus")
     L = len(alignments)
     if pi is None:
         hist = eng.state_histogram(states, offsets, device=device)
         pi = nexus.base_frequencies_from_histogram(hist)
     pi = np.asarray(pi, dtype=np.float64).reshape(L, 4)
+    lap("base_frequencies")
     if exch is None:
         exch = model_averaged_exchangeabilities(eng, states, offsets, pi, len(leaf_names), parent, blen, leaf, T, times,
                                                 intervals, correction, device)
+        lap("stage1_model_averaging")
     exch = np.asarray(exch, dtype=np.float64)
     if exch.ndim == 1:
         exch = np.tile(exch, (L, 1))
@@ -207,9 +223,10 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
         if need_subset:
             out = plan.site_rates(states)
         else:
-            out = plan.run_fused(states)
+            out = plan.run_fused(states, pinned=True) if pinned else plan.run_fused(states)
     finally:
         plan.close()
+    lap("site_rates_and_pi_incl_pcie")
     # what tapir would have after parse_site_rates + cull (bin/tapir_compute.py:100-102)
     rate4 = compute.round_like_hyphy(out["rate"], round_decimals) if round_decimals >= 0 else out["rate"]
     corrected = rate4 / correction
@@ -221,6 +238,7 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
         if base in subsets:
             r = r[subsets[base][0]:subsets[base][1]]
         per_locus.append(r)
+    lap("round_correct_cull")
     if output_dir is not None:
         paths = [os.path.join(output_dir, os.path.basename(a) + ".rates") for a in alignments]
         if pool is not None and L > 1:
@@ -247,10 +265,12 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     elif progress:
         for _ in alignments:
             progress()
+    lap("write_rates_files")
     if need_subset:
         tables = _tables_for_rates(eng, per_locus, leaf_names, parent, blen, leaf, T, times, intervals, device, integ_mode)
     else:
         tables = out["tables"]
+    out["timings"] = timings
     out["final_tables"] = tables   # [L, W] rows as stored in sqlite (after any subset slicing)
     return _tuples(alignments, per_locus, tables, T, times, intervals), out
 
