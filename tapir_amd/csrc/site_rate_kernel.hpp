@@ -306,7 +306,11 @@ __device__ __forceinline__ uint32_t pick_word(const uint32_t (&pk)[NW > 0 ? NW :
 //         (L2-resident: 4 bytes per 8 tips per evaluation) when word w is started, i.e. eight ops before it is needed;
 // NW = 0: states are fetched from the byte array one op ahead (the eval_columns diagnostic, which thereby
 //         cross-checks the packed paths, and TPHIP_FORCE_BYTE_PATH).
-template <int NW>
+// SPILL: the parked partials beyond the first P.lds_depth live in a global scratch row of this wave (L2-resident)
+//        instead of LDS.  On a deep tree (256 taxa: 4 parked partials = 24 KB of LDS per wave) the LDS stack, not the
+//        registers, caps the CU at 6 waves; the deepest slot is used by ~1 push in 9, so parking it in global memory
+//        costs little and lets 8 waves (2 per SIMD) stay resident.
+template <int NW, bool SPILL = false>
 __device__ __forceinline__ void evaluate_column(const SiteParams& P, const ModelRegs& R, const double* __restrict__ wtab,
                                                 const double* __restrict__ etab, double* __restrict__ stack, int64_t col,
                                                 const uint32_t (&pk)[NW > 0 ? NW : 1], double s, double& f,
@@ -371,24 +375,44 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
         }
         const int code = op.code & OP_CODE_MASK;   // the fused stream ORs OP_PUSH_BEFORE / OP_POP_AFTER into the code
         auto park = [&]() {     // PUSH: the finished sibling goes to the LDS stack; the TIP_SET / CHERRY that always
-            double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;   // follows overwrites the accumulator
+            if (SPILL && sp >= P.lds_depth) {   // follows overwrites the accumulator        (sp is wave-uniform)
+                double* slot = P.spill + ((size_t)blockIdx.x * (size_t)(P.stack_depth - P.lds_depth) + (size_t)(sp - P.lds_depth)) * 12 * kSiteBlock + lane;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                slot[(i)*kSiteBlock] = acc.v[i];
-                slot[(4 + i) * kSiteBlock] = acc.d1[i];
-                slot[(8 + i) * kSiteBlock] = acc.d2[i];
+                for (int i = 0; i < 4; ++i) {
+                    slot[(i)*kSiteBlock] = acc.v[i];
+                    slot[(4 + i) * kSiteBlock] = acc.d1[i];
+                    slot[(8 + i) * kSiteBlock] = acc.d2[i];
+                }
+            } else {
+                double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    slot[(i)*kSiteBlock] = acc.v[i];
+                    slot[(4 + i) * kSiteBlock] = acc.d1[i];
+                    slot[(8 + i) * kSiteBlock] = acc.d2[i];
+                }
             }
             ++sp;
         };
         auto pop_mul = [&]() {  // POP_MUL: acc *= parked sibling
             Partial m;
             --sp;
-            const double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
+            if (SPILL && sp >= P.lds_depth) {
+                const double* slot = P.spill + ((size_t)blockIdx.x * (size_t)(P.stack_depth - P.lds_depth) + (size_t)(sp - P.lds_depth)) * 12 * kSiteBlock + lane;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                m.v[i] = slot[(i)*kSiteBlock];
-                m.d1[i] = slot[(4 + i) * kSiteBlock];
-                m.d2[i] = slot[(8 + i) * kSiteBlock];
+                for (int i = 0; i < 4; ++i) {
+                    m.v[i] = slot[(i)*kSiteBlock];
+                    m.d1[i] = slot[(4 + i) * kSiteBlock];
+                    m.d2[i] = slot[(8 + i) * kSiteBlock];
+                }
+            } else {
+                const double* slot = stack + (size_t)sp * 12 * kSiteBlock + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m.v[i] = slot[(i)*kSiteBlock];
+                    m.d1[i] = slot[(4 + i) * kSiteBlock];
+                    m.d2[i] = slot[(8 + i) * kSiteBlock];
+                }
             }
             partial_mul(acc, m);
         };
@@ -456,7 +480,7 @@ __device__ __forceinline__ void evaluate_column(const SiteParams& P, const Model
 // L(s) = sum_k w_k L(s rho_k) -- the "+G" of GTR+G as an opt-in extension the reference's script does not have
 // (SURVEY F2).  With f_k, g_k, h_k the category's log-likelihood and u-derivatives and p_k its posterior weight:
 // f = logsumexp(log w_k + f_k), g = sum p_k g_k, h = sum p_k (h_k + g_k^2) - g^2 (running maximum, one pass).
-template <int NW>
+template <int NW, bool SPILL = false>
 __device__ __forceinline__ void evaluate_site(const SiteParams& P, const ModelRegs& R, const double* __restrict__ wtab,
                                               const double* __restrict__ etab, double* __restrict__ stack, int64_t col,
                                               const uint32_t (&pk)[NW > 0 ? NW : 1], double s, double& f, double& g,
@@ -465,7 +489,7 @@ __device__ __forceinline__ void evaluate_site(const SiteParams& P, const ModelRe
     double top = -INFINITY, z = 0.0, a = 0.0, b = 0.0;
     for (int k = 0; k < K; ++k) {
         double fk, gk, hk;
-        evaluate_column<NW>(P, R, wtab, etab, stack, col, pk, P.ncat > 1 ? s * P.cat[k] : s, fk, gk, hk);
+        evaluate_column<NW, SPILL>(P, R, wtab, etab, stack, col, pk, P.ncat > 1 ? s * P.cat[k] : s, fk, gk, hk);
         if (P.ncat <= 1) { f = fk; g = gk; h = hk; return; }
         fk += P.cat[K + k];
         if (fk > top) {
@@ -540,7 +564,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* __rest
 #ifndef TPHIP_SITE_MIN_WAVES
 #define TPHIP_SITE_MIN_WAVES 1
 #endif
-template <int NW>
+template <int NW, bool SPILL = false>
 __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_kernel(SiteParams P) {
     extern __shared__ double lds[];
     double* wtab = lds;          // [16 masks][4]
@@ -629,7 +653,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         int it = 0;
         while (true) {
             double f, g, h;
-            evaluate_site<NW>(P, R, wtab, etab, stack, col, pk, exp(u), f, g, h);
+            evaluate_site<NW, SPILL>(P, R, wtab, etab, stack, col, pk, exp(u), f, g, h);
             if (!done) {
                 ++evals;
                 ++it;

@@ -20,6 +20,7 @@ hipError_t launch_site_rate_kernel(int variant, dim3 grid, size_t lds_bytes, hip
     else if (variant == 2) site_rate_kernel<2><<<grid, block, lds_bytes, st>>>(S);
     else if (variant == 8) site_rate_kernel<8><<<grid, block, lds_bytes, st>>>(S);
     else if (variant == kStreamWords) site_rate_kernel<kStreamWords><<<grid, block, lds_bytes, st>>>(S);
+    else if (variant == kStreamWordsSpill) site_rate_kernel<kStreamWords, true><<<grid, block, lds_bytes, st>>>(S);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -30,6 +31,8 @@ hipError_t site_rate_kernel_occupancy(int variant, size_t lds_bytes, int* blocks
     if (variant == 8) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<8>, kSiteBlock, lds_bytes);
     if (variant == kStreamWords)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<kStreamWords>, kSiteBlock, lds_bytes);
+    if (variant == kStreamWordsSpill)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<kStreamWords, true>, kSiteBlock, lds_bytes);
     return hipErrorInvalidValue;
 }
 

@@ -60,6 +60,8 @@ struct SiteParams {
     double* lnl;
     uint8_t* flag;
     unsigned long long* eval_counter;
+    double* spill;                 // SPILL variant: [grid waves][stack_depth - lds_depth][12][64] parked partials beyond the LDS stack
+    int32_t lds_depth;             // parked partials kept in LDS (= stack_depth unless the SPILL variant runs)
 };
 
 // Slices a locus with `count` optimiser columns is cut into in the non-persistent mode: about chunk_cols each.
@@ -70,6 +72,7 @@ __host__ __device__ __forceinline__ int site_slices(int count, int chunk_cols) {
 }
 
 constexpr int kStreamWords = -1;   // NW value of the streamed-words path
+constexpr int kStreamWordsSpill = -2;   // launcher variant: streamed words + SPILL
 
 // Diagnostic launch: evaluate f = log L, g = df/du, h = d2f/du2 at a caller-chosen u for EVERY column.
 struct EvalParams {
@@ -81,7 +84,8 @@ struct EvalParams {
 };
 
 // ---- launchers defined in site_rate_launch.hip ------------------------------------------------------------------
-// variant: 0 = byte path (NW = 0), 2 / 8 = packed words in registers, kStreamWords = streamed words (> 64 tips)
+// variant: 0 = byte path (NW = 0), 2 / 8 = packed words in registers, kStreamWords = streamed words (> 64 tips),
+// kStreamWordsSpill = the same with the deepest parked partials in global scratch (S.spill, S.lds_depth)
 hipError_t launch_site_rate_kernel(int variant, dim3 grid, size_t lds_bytes, hipStream_t st, const SiteParams& S);
 hipError_t site_rate_kernel_occupancy(int variant, size_t lds_bytes, int* blocks_per_cu);
 hipError_t launch_eval_columns_kernel(dim3 grid, size_t lds_bytes, hipStream_t st, const EvalParams& E);

@@ -127,6 +127,8 @@ struct tphip_plan {
     int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
     int32_t site_persistent = 1;
     int32_t site_grid_mult = 1;   // persistent grid = resident waves x this (see plan creation)
+    int32_t site_lds_depth = 0;   // parked partials kept in LDS by site_rate_kernel (< stack depth: SPILL variant)
+    size_t ws_spill = 0;
     double site_first_fraction = 0.0;   // share of the work the first round of shares takes (0 = equal shares)
     bool force_byte_path = false;       // TPHIP_FORCE_BYTE_PATH=1 at plan creation: run the NW = 0 kernel on any tree (tests)
     // profiling
@@ -333,6 +335,26 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         if (oe != hipSuccess || per_cu < 1) per_cu = 1;
         p->site_waves = per_cu * prop.multiProcessorCount;
         p->num_cus = prop.multiProcessorCount;
+        // Deep trees (256 taxa: 4 parked partials = 24 KB per wave) are capped at 6 waves per CU by the LDS stack, not by
+        // the registers.  The deepest slots are the least used (C5 tree: 9 of 80 pushes per evaluation reach the fourth),
+        // so the streamed-words kernel has a variant that parks them in a global scratch row of the wave instead: with
+        // three slots in LDS (19.7 KB) eight waves fit.  Only worth it for the persistent grid (one scratch row per wave).
+        p->site_lds_depth = p->prog.stack_depth;
+        {
+            const int keep = (int)((160 * 1024 / 8 - kSiteLdsHeader * sizeof(double)) / (12 * kSiteBlock * sizeof(double)));   // = 3
+            bool want = p->nwords > 8 && p->prog.stack_depth > keep && per_cu < 8;
+            if (const char* es = getenv("TPHIP_SITE_SPILL")) want = (es[0] == '1') && p->nwords > 8 && p->prog.stack_depth > 1;
+            if (want) {
+                const int depth = std::max(1, std::min(keep, p->prog.stack_depth - 1));
+                const size_t lds2 = (kSiteLdsHeader + (size_t)depth * 12 * kSiteBlock) * sizeof(double);
+                int per2 = 0;
+                if (site_rate_kernel_occupancy(kStreamWordsSpill, lds2, &per2) == hipSuccess && per2 > per_cu &&
+                    ncols / ((int64_t)per2 * prop.multiProcessorCount) >= 1000) {   // persistent mode will be chosen below
+                    p->site_lds_depth = depth;
+                    p->site_waves = per2 * prop.multiProcessorCount;
+                }
+            }
+        }
         // locus likelihood (value) kernel: staging the state masks in LDS costs it more than it saves (measured 13.6 ms
         // vs 10.0 ms per 1616 candidates x 20000 columns x 64 taxa); opt-in for experiments
         p->lik_lds = ((size_t)p->nnodes * 4 + (size_t)p->prog.stack_depth * 4 * kLikBlock) * sizeof(double);
@@ -369,6 +391,10 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         // slice instead: cutting a small locus in two doubles its prologue and drain (measured on C2).
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
         if (const char* e3 = getenv("TPHIP_SITE_PERSISTENT")) p->site_persistent = (e3[0] == '1');
+        if (!p->site_persistent && p->site_lds_depth < p->prog.stack_depth) {   // the scratch rows are per persistent wave
+            p->site_lds_depth = p->prog.stack_depth;
+            p->site_waves = per_cu * prop.multiProcessorCount;
+        }
         if (const char* e2 = getenv("TPHIP_SITE_WAVES")) { long v = atol(e2); if (v >= 1) p->site_waves = (int32_t)v; }  // tuning knob
         // Share sizes of the persistent grid.  Equal shares (one per resident wave) are equal column counts, not equal
         // work: loci differ in evaluations per column, and with 5-7 resident waves per CU (deep LDS stacks) a wave that
@@ -405,6 +431,10 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         p->ws_tab_key = off; off = align_up(off + sizeof(unsigned long long) * 2 * (size_t)ncols, 256);
         p->ws_tab_val = off; off = align_up(off + sizeof(int32_t) * 2 * (size_t)ncols, 256);
         p->ws_dedup_on = off; off = align_up(off + sizeof(int32_t) * (size_t)d->nloci, 256);
+    }
+    if (p->site_lds_depth < p->prog.stack_depth) {
+        const size_t rows = (size_t)p->site_waves * (size_t)p->site_grid_mult * (size_t)(p->prog.stack_depth - p->site_lds_depth);
+        p->ws_spill = off; off = align_up(off + rows * 12 * kSiteBlock * sizeof(double), 256);
     }
     p->ws_total = off + 256;
     *out = p;
@@ -544,7 +574,10 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.work_prefix = (const int64_t*)((char*)ws + p->ws_work_prefix); S.nloci = p->nloci;
     S.slice_prefix = (const int64_t*)((char*)ws + p->ws_slice_prefix);
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
-    const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+    const bool spill = p->site_lds_depth < p->prog.stack_depth;
+    const size_t lds = (kSiteLdsHeader + (size_t)p->site_lds_depth * 12 * kSiteBlock) * sizeof(double);
+    S.lds_depth = p->site_lds_depth;
+    S.spill = spill ? (double*)((char*)ws + p->ws_spill) : nullptr;
     S.persistent = p->site_persistent;
     S.first_round = p->site_waves;
     S.first_fraction = (p->site_first_fraction > 0.0) ? p->site_first_fraction : 1.0 / (double)p->site_grid_mult;
@@ -560,7 +593,10 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
             S.nops = (int32_t)p->prog.fused_ops.size();
         }
         // variants: byte path; packed words in registers (<= 16 / <= 64 tips); streamed words (more than 64 tips)
-        HIP_TRY(launch_site_rate_kernel(byte_path ? 0 : p->nwords <= 2 ? 2 : p->nwords <= 8 ? 8 : kStreamWords, grid, lds, st, S));
+        const size_t lds_full = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+        const int variant = byte_path ? 0 : p->nwords <= 2 ? 2 : p->nwords <= 8 ? 8 : (spill ? kStreamWordsSpill : kStreamWords);
+        if (byte_path) { S.lds_depth = p->prog.stack_depth; S.spill = nullptr; }
+        HIP_TRY(launch_site_rate_kernel(variant, grid, (byte_path || !spill) ? lds_full : lds, st, S));
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));
     if (dedup) dedup_scatter_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
@@ -1024,7 +1060,7 @@ int tphip_eval_columns_dev(tphip_plan* p, const uint8_t* d_s, const double* d_u,
     E.S.chunk_cols = p->site_chunk_cols;
     E.S.packed = nullptr; E.S.nwords = 0;
     E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
-    E.S.flag = nullptr; E.S.eval_counter = nullptr;
+    E.S.flag = nullptr; E.S.eval_counter = nullptr; E.S.spill = nullptr; E.S.lds_depth = p->prog.stack_depth;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
     if (p->n_site_chunks > 0) HIP_TRY(launch_eval_columns_kernel(dim3((unsigned)p->n_site_chunks), lds, (hipStream_t)stream, E));

@@ -130,6 +130,30 @@ def test_fullsize_properties(workload, oracle):
     torch.cuda.empty_cache()
 
 
+def test_deep_tree_spilled_stack_is_bit_identical(monkeypatch):
+    """256 taxa: the persistent site-rate kernel keeps three parked partials in LDS and the fourth in a global scratch
+    row per wave (8 resident waves per CU instead of 6; tphip.hip plan creation).  Same bits as with the whole stack in
+    LDS, on an eighth of C5 (2.5 M columns: the persistent grid, so the spill variant is the one that runs)."""
+    import torch
+    from tapir_amd import engine, synth
+    nloci, ncols, ntaxa, times, intervals = synth.WORKLOADS["C5"]
+    nloci //= 8
+    seed = synth.WORKLOAD_SEED["C5"]
+    d = synth.simulate(nloci, ncols, ntaxa, seed, device="cuda", tree=synth.yule_tree(ntaxa, seed))
+    pin = synth.plan_inputs(d["root"], d["names"])
+    outs = {}
+    for spill in ("0", "1"):
+        monkeypatch.setenv("TPHIP_SITE_SPILL", spill)
+        plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"],
+                           times, intervals, correction=pin["correction"])
+        assert plan.stack_depth == 4
+        outs[spill] = (_run(torch, plan, d["states"], nloci), plan.workspace_bytes)
+        plan.close()
+    assert outs["1"][1] > outs["0"][1]          # the scratch rows are part of the workspace: the variant did run
+    for k in outs["0"][0]:
+        assert torch.equal(outs["0"][0][k], outs["1"][0][k]), k
+
+
 _PORT = [29630]
 
 
