@@ -250,7 +250,8 @@ class Stage1:
     """Model-averaged exchangeabilities for every locus of a plan (see module docstring)."""
 
     def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, analytic=None, sub_analytic=None, prune_models=True,
-                 precondition=True, verbose=False):
+                 precondition=True, verbose=False, screen_models=True):
+        self.screen_models = screen_models   # quadratic screen of the 202 constrained models (see _screen_submodels)
         self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
         self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
         self.pi = self.pi / self.pi.sum(1, keepdims=True)
@@ -455,6 +456,8 @@ class Stage1:
             for c in range(D):
                 g[:, c] = (dr * (cls == c)).sum(1)
             self._sub_last_f[idx] = -lnl
+            if self._sub_hdiag is not None:
+                return -lnl, -np.where(self._sub_active[idx], g, 0.0), self._sub_hdiag[idx]
             return -lnl, -np.where(self._sub_active[idx], g, 0.0)
         # central differences: the stencil's exchangeabilities are the base point's times precomputed factors
         # (member rates of class j times e^{+-h}), so a whole iteration's candidates are two broadcasts
@@ -470,7 +473,76 @@ class Stage1:
         f = f.reshape(n, per)
         g = (f[:, 1::2] - f[:, 2::2]) / (2 * self.h)
         self._sub_last_f[idx] = f[:, 0]
+        if self._sub_hdiag is not None:
+            return f[:, 0], np.where(self._sub_active[idx], g, 0.0), self._sub_hdiag[idx]
         return f[:, 0], np.where(self._sub_active[idx], g, 0.0)
+
+    # ---- quadratic screen of the 202 constrained models ------------------------------------------------------
+    # Every constrained model maximises THE SAME function as the general model -- f(rho) = lnL at the stashed branch
+    # lengths b* (in expected substitutions, bf:522-540, 613-619) as a function of the five log-rates rho -- over a linear
+    # subspace: rates of one class are equal, the class of AG is 0 (bf:577-600), i.e. rho = A_m theta.  So one local
+    # model of f serves all 202: its Hessian at the general model's optimum (31 likelihood evaluations per locus) gives
+    # every model's constrained optimum in closed form, theta_m = (A'HA)^-1 A'(H rho* - g).  One TRUE likelihood
+    # evaluation there (202 per locus) then tells which models can carry weight at all: on long loci a handful -- the
+    # others trail by hundreds of log-units and are never fitted (before: one 9-point stencil iteration for each of
+    # them, 90 % of the stage's kernel time at 50 000 columns) -- and the fitted ones start next to their optimum with
+    # the right metric.  Nothing is approximated in what is reported: a fitted model is polished on the true likelihood
+    # as before, an abandoned one carries its true likelihood at theta_m (a lower bound of its maximum).
+    def _screen_submodels(self, grm_exch, cls, kk, h=2e-2):
+        L = self.plan.nloci
+        M = cls.shape[0]
+        free6 = np.array([0, 2, 3, 4, 5])                   # positions of AC, AT, CG, CT, GT among the six rates
+        rho = np.log(grm_exch[:, free6])                     # [L, 5]
+        pairs = [(i, j) for i in range(5) for j in range(i + 1, 5)]
+        pts = [np.zeros(5)]
+        for i in range(5):
+            for sgn in (1.0, -1.0):
+                e = np.zeros(5); e[i] = sgn * h; pts.append(e)
+        for i, j in pairs:
+            for sgn in (1.0, -1.0):
+                e = np.zeros(5); e[i] = sgn * h; e[j] = sgn * h; pts.append(e)
+        pts = np.array(pts)                                   # [31, 5]
+        npts = len(pts)
+        loc = np.repeat(np.arange(L), npts)
+        logr = (rho[:, None, :] + pts[None, :, :]).reshape(-1, 5)
+        exch = self._exch_from_free(logr)
+        scale = 1.0 / (exch * self._w6[loc]).sum(axis=1)
+        f = self._lik(self._stash, loc, exch, loc, scale).reshape(L, npts)
+        f0 = f[:, 0]
+        g = np.zeros((L, 5)); H = np.zeros((L, 5, 5))
+        for i in range(5):
+            fp, fm = f[:, 1 + 2 * i], f[:, 2 + 2 * i]
+            g[:, i] = (fp - fm) / (2 * h)
+            H[:, i, i] = (fp - 2 * f0 + fm) / (h * h)
+        for q, (i, j) in enumerate(pairs):
+            fpp, fmm = f[:, 11 + 2 * q], f[:, 12 + 2 * q]
+            fi = f[:, 1 + 2 * i] + f[:, 2 + 2 * i]
+            fj = f[:, 1 + 2 * j] + f[:, 2 + 2 * j]
+            H[:, i, j] = H[:, j, i] = (fpp + fmm - fi - fj + 2 * f0) / (2 * h * h)
+        # curvature of -f, made safely positive definite (a rate on the edge of its box, or a flat direction)
+        w, V = np.linalg.eigh(-H)
+        floor = np.maximum(1e-6 * np.abs(w).max(axis=1, keepdims=True), 1e-8)
+        K = np.einsum("lik,lk,ljk->lij", V, np.maximum(w, floor), V)      # [L, 5, 5]
+        self._screen_K, self._screen_g = K, g
+        # constrained optimum of the quadratic model per (locus, model)
+        theta = np.zeros((L, M, 4))
+        hdiag = np.full((L, M, 4), np.nan)
+        for m in range(M):
+            k = int(kk[m])
+            A = np.zeros((5, max(k, 1)))
+            for q5, q6 in enumerate(free6):
+                if cls[m, q6] >= 0:
+                    A[q5, cls[m, q6]] = 1.0
+            if k == 0:
+                continue
+            A = A[:, :k]
+            AK = np.einsum("qa,lqr->lar", A, K)                # [L, k, 5]
+            AKA = np.einsum("lar,rb->lab", AK, A)              # [L, k, k]
+            rhs = np.einsum("lar,lr->la", AK, rho) + g @ A     # maximise f: K (A theta - rho*) = g  (g is d f / d rho)
+            theta[:, m, :k] = np.linalg.solve(AKA, rhs[..., None])[..., 0]
+            hdiag[:, m, :k] = np.einsum("laa->la", AKA)
+        theta = np.clip(theta, LOG_RATE_MIN, LOG_RATE_MAX)
+        return theta.reshape(L * M, 4), hdiag.reshape(L * M, 4)
 
     def fit_submodels(self, grm_exch, grm_t, maxit=100, grm_lnl=None):
         L = self.plan.nloci
@@ -496,13 +568,19 @@ class Stage1:
             need[:, 1 + 2 * j] = need[:, 2 + 2 * j] = k[1:] > j
         self._sub_stencil = np.tile(sten, (L, 1, 1))
         self._sub_need = np.tile(need, (L, 1))
-        # start: geometric mean of the general model's rates over each class
-        lg = np.log(grm_exch)[self._sub_locus]                        # [P, 6]
-        x0 = np.zeros((L * M, 4))
-        for c in range(4):
-            inc = self._sub_cls == c
-            cnt = inc.sum(1)
-            x0[:, c] = np.where(cnt > 0, (lg * inc).sum(1) / np.maximum(cnt, 1), 0.0)
+        self._sub_hdiag = None
+        if self.screen_models:
+            # start: every model's optimum under the shared quadratic model of the likelihood (_screen_submodels)
+            x0, self._sub_hdiag = self._screen_submodels(grm_exch, cls[1:], k[1:])
+            x0 = np.where(self._sub_active, x0, 0.0)
+        else:
+            # start: geometric mean of the general model's rates over each class
+            lg = np.log(grm_exch)[self._sub_locus]                        # [P, 6]
+            x0 = np.zeros((L * M, 4))
+            for c in range(4):
+                inc = self._sub_cls == c
+                cnt = inc.sum(1)
+                x0[:, c] = np.where(cnt > 0, (lg * inc).sum(1) / np.maximum(cnt, 1), 0.0)
         # Models that cannot matter are abandoned early: a model whose Akaike score lnL - k trails the best of its
         # locus by more than PRUNE_NATS even after crediting three times its last improvement carries a weight below
         # e^-30 ~ 1e-13 -- invisible in the averaged rates -- so polishing its optimum is wasted likelihood evaluations
@@ -510,22 +588,63 @@ class Stage1:
         best = (np.asarray(grm_lnl) - 5.0).copy() if grm_lnl is not None else np.full(L, -np.inf)
         self.pruned = 0
 
-        def prune(idx, f, df):
-            score = -f - kk[idx]
-            loc = self._sub_locus[idx]
-            np.maximum.at(best, loc, score)
-            drop = score + 3.0 * np.maximum(df, 0.0) < best[loc] - PRUNE_NATS
-            self.pruned += int(drop.sum())
-            return drop
-
         self._sub_last_f = np.zeros(L * M)
         self._sub_kicks = np.zeros(L * M, dtype=np.int64)
-        opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0, active=self._sub_active, maxit=maxit,
-                     lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune if self.prune_models else None, escape=self._sub_escape)
-        x, f = opt.run()
-        self.sub_iters = opt.iters
+        sel = None
+        if self.screen_models and self.prune_models and grm_lnl is not None:
+            # one true likelihood per model at its screened optimum; a model that trails the best of its locus by more than
+            # PRUNE_NATS even after crediting three times what the quadratic model missed there is never fitted
+            f_at = self._sub_value(x0, np.arange(L * M))                          # -lnL at the screened optima
+            score = -f_at - kk
+            np.maximum.at(best, self._sub_locus, score)
+            rho5 = np.log(grm_exch[:, [0, 2, 3, 4, 5]])[self._sub_locus]
+            A_theta = np.where(self._sub_cls[:, [0, 2, 3, 4, 5]] >= 0,
+                               x0[np.arange(L * M)[:, None], np.maximum(self._sub_cls[:, [0, 2, 3, 4, 5]], 0)], 0.0)
+            # what the quadratic model (metric K of the locus) predicted for this point vs what the likelihood says
+            keep = score + 3.0 * np.abs(self._screen_miss(A_theta - rho5, f_at, grm_lnl)) >= best[self._sub_locus] - PRUNE_NATS
+            self.pruned = int((~keep).sum())
+            sel = np.flatnonzero(keep)
+            self._sub_last_f[:] = f_at
+        if sel is None:
+            sel = np.arange(L * M)
+        x, fall = x0.copy(), self._sub_last_f.copy()
+        self.sub_iters = np.zeros(L * M, dtype=np.int64)
+        if sel.size:
+            full = dict(cls=self._sub_cls, locus=self._sub_locus, active=self._sub_active, stencil=self._sub_stencil,
+                        need=self._sub_need, hdiag=self._sub_hdiag, kk=kk)
+            # the optimiser sees the surviving problems only
+            self._sub_cls, self._sub_locus, self._sub_active = full["cls"][sel], full["locus"][sel], full["active"][sel]
+            self._sub_stencil, self._sub_need = full["stencil"][sel], full["need"][sel]
+            self._sub_hdiag = None if full["hdiag"] is None else full["hdiag"][sel]
+            self._sub_last_f = np.zeros(sel.size)
+            self._sub_kicks = np.zeros(sel.size, dtype=np.int64)
+            kk_sel = kk[sel]
+
+            def prune_sel(idx, f, df):
+                score = -f - kk_sel[idx]
+                loc = self._sub_locus[idx]
+                np.maximum.at(best, loc, score)
+                drop = score + 3.0 * np.maximum(df, 0.0) < best[loc] - PRUNE_NATS
+                self.pruned += int(drop.sum())
+                return drop
+
+            opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0[sel], active=self._sub_active, maxit=maxit,
+                         lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune_sel if self.prune_models else None, escape=self._sub_escape)
+            xs, fs = opt.run()
+            x[sel], fall[sel] = xs, fs
+            self.sub_iters[sel] = opt.iters
+            self._sub_cls, self._sub_locus, self._sub_active = full["cls"], full["locus"], full["active"]
+            self._sub_stencil, self._sub_need, self._sub_hdiag = full["stencil"], full["need"], full["hdiag"]
         exch = self._sub_exch(x, self._sub_cls).reshape(L, M, 6)
-        return exch, (-f).reshape(L, M), k
+        return exch, (-fall).reshape(L, M), k
+
+    def _screen_miss(self, delta, f_at, grm_lnl):
+        """How far the true likelihood at a screened optimum is from what the quadratic model predicted there (the
+        model's error is the scale of what a fit can still gain): predicted -lnL = -lnL* + 1/2 delta' K delta."""
+        K = self._screen_K[self._sub_locus]
+        pred = -np.asarray(grm_lnl)[self._sub_locus] - np.einsum("pq,pq->p", self._screen_g[self._sub_locus], delta) \
+            + 0.5 * np.einsum("pi,pij,pj->p", delta, K, delta)
+        return f_at - pred
 
     # ---- model averaging (bf:806-847) --------------------------------------------------------------------
     def run(self):
