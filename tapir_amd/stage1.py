@@ -521,7 +521,9 @@ class Stage1:
             H[:, i, j] = H[:, j, i] = (fpp + fmm - fi - fj + 2 * f0) / (2 * h * h)
         # curvature of -f, made safely positive definite (a rate on the edge of its box, or a flat direction)
         w, V = np.linalg.eigh(-H)
-        floor = np.maximum(1e-6 * np.abs(w).max(axis=1, keepdims=True), 1e-8)
+        # (absolute floor 1e-3: a direction along which lnL changes by less than 5e-4 per unit of log-rate is flat for
+        #  every purpose; on a locus without data the stencil's gradient is rounding noise, which a smaller floor amplifies)
+        floor = np.maximum(1e-6 * np.abs(w).max(axis=1, keepdims=True), 1e-3)
         K = np.einsum("lik,lk,ljk->lij", V, np.maximum(w, floor), V)      # [L, 5, 5]
         self._screen_K, self._screen_g = K, g
         # constrained optimum of the quadratic model per (locus, model)
