@@ -36,7 +36,7 @@ LOG_BLEN_MIN, LOG_BLEN_MAX = -23.0, 4.0     # branch lengths within [1e-10, 55]
 MAX_LOG_STEP = 2.0                          # largest move of a log-parameter in one iteration
 ESCAPE_RATE = 0.05                          # where a wrongly collapsed exchangeability is put back (Stage1._sub_escape)
 ESCAPE_LENGTH = 1e-3                        # where a wrongly collapsed branch is put back (Stage1._grm_escape)
-PRUNE_NATS = 30.0                           # see Stage1.fit_submodels
+PRUNE_NATS = 21.0                           # see Stage1.fit_submodels: a model this far behind weighs < e^-21 = 8e-10
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
 
 
@@ -98,7 +98,7 @@ class _LBFGS:
         P, D = self.x.shape
         self.lo, self.hi = np.broadcast_to(lo, (D,)), np.broadcast_to(hi, (D,))
         self.active = np.ones((P, D), bool) if active is None else active
-        self.m, self.maxit, self.ftol, self.gtol = history, maxit, ftol, gtol
+        self.m, self.maxit, self.ftol, self.gtol = min(history, max(D, 2)), maxit, ftol, gtol   # D pairs span R^D
 
     def _vg(self, x, idx):
         out = self.vg(x, idx)
@@ -585,7 +585,7 @@ class Stage1:
                 x0[:, c] = np.where(cnt > 0, (lg * inc).sum(1) / np.maximum(cnt, 1), 0.0)
         # Models that cannot matter are abandoned early: a model whose Akaike score lnL - k trails the best of its
         # locus by more than PRUNE_NATS even after crediting three times its last improvement carries a weight below
-        # e^-30 ~ 1e-13 -- invisible in the averaged rates -- so polishing its optimum is wasted likelihood evaluations
+        # e^-21 ~ 8e-10 -- invisible in the averaged rates -- so polishing its optimum is wasted likelihood evaluations
         # (with thousands of columns all but a handful of the 203 models are in that state after one iteration).
         best = (np.asarray(grm_lnl) - 5.0).copy() if grm_lnl is not None else np.full(L, -np.inf)
         self.pruned = 0
