@@ -87,7 +87,7 @@ def main():
                     help="default: C3 on one GPU (the headline), C4 dealt over the ranks when --gpus > 1")
     ap.add_argument("--loci", type=int, default=None, help="override the number of loci of the config (experiments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration per leg (0 = skip)")
-    ap.add_argument("--stage1-loci", type=int, default=4,
+    ap.add_argument("--stage1-loci", type=int, default=16,
                     help="also time HyPhy's stage 1 (model-averaged exchangeabilities) on the first N loci (0 = skip)")
     ap.add_argument("--gamma-categories", type=int, default=1,
                     help="K > 1: opt-in discrete-gamma rate mixture in the site-rate stage (alpha 0.5); not the headline config")
