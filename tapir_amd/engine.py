@@ -330,6 +330,14 @@ class Plan:
                                             out.ctypes.data))
         return out
 
+    def locus_loglik_dev(self, d_states_ptr, ncand, d_cand_locus, d_cand_exch, d_blen_vecs, d_cand_vec, d_cand_scale,
+                         d_cand_pidx, d_cand_pfac, d_out, stream=0):
+        """tphip_locus_loglik_dev: every array is a device tensor (int32 / float64), nothing is copied or synchronised.
+        d_states_ptr: device address of the alignment (int, e.g. the pointer a device_cache() holds)."""
+        _check(self._lib.tphip_locus_loglik_dev(self._h, d_states_ptr, int(ncand), _ptr(d_cand_locus), _ptr(d_cand_exch),
+                                                _ptr(d_blen_vecs), _ptr(d_cand_vec), _ptr(d_cand_scale), _ptr(d_cand_pidx),
+                                                _ptr(d_cand_pfac), _ptr(d_out), stream))
+
     def locus_gradient(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
                        cand_pfac=None, cache=None, per_branch=True, curvature=False):
         """locus_loglik plus its derivatives (tphip_locus_gradient): returns (lnl[n], dexch[n, 6], dlogt[n, nnodes] or

@@ -250,8 +250,10 @@ class Stage1:
     """Model-averaged exchangeabilities for every locus of a plan (see module docstring)."""
 
     def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, analytic=None, sub_analytic=None, prune_models=True,
-                 precondition=True, verbose=False, screen_models=True):
+                 precondition=True, verbose=False, screen_models=True, device_fit=True):
         self.screen_models = screen_models   # quadratic screen of the 202 constrained models (see _screen_submodels)
+        self.device_fit = device_fit         # fit the surviving models with the device-resident optimiser (stage1_device.py)
+        self.sub_device = False
         self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
         self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
         self.pi = self.pi / self.pi.sum(1, keepdims=True)
@@ -630,11 +632,25 @@ class Stage1:
                 self.pruned += int(drop.sum())
                 return drop
 
-            opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0[sel], active=self._sub_active, maxit=maxit,
-                         lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune_sel if self.prune_models else None, escape=self._sub_escape)
-            xs, fs = opt.run()
+            from . import stage1_device
+            if self.device_fit and not self.sub_analytic and self._sub_hdiag is not None and stage1_device.available(self.plan) \
+                    and self.cache.ptr:
+                # optimiser state on the GPU (stage1_device.py): no host round trip per likelihood call
+                fit = stage1_device.DeviceSubmodelFitter(self.plan, self.cache.ptr.value, self._stash, self._w6, self._sub_locus,
+                                                         self._sub_cls, self._sub_active, self._sub_stencil, self._sub_need,
+                                                         kk_sel, self.h, device=self.plan.device)
+                xs, fs, its = fit.run(x0[sel], self._sub_hdiag, best, maxit=maxit, prune=self.prune_models)
+                self.nevals += fit.nevals
+                self.pruned += fit.pruned
+                self.sub_device = True
+            else:
+                opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0[sel], active=self._sub_active, maxit=maxit,
+                             lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune_sel if self.prune_models else None,
+                             escape=self._sub_escape)
+                xs, fs = opt.run()
+                its = opt.iters
             x[sel], fall[sel] = xs, fs
-            self.sub_iters[sel] = opt.iters
+            self.sub_iters[sel] = its
             self._sub_cls, self._sub_locus, self._sub_active = full["cls"], full["locus"], full["active"]
             self._sub_stencil, self._sub_need, self._sub_hdiag = full["stencil"], full["need"], full["hdiag"]
         exch = self._sub_exch(x, self._sub_cls).reshape(L, M, 6)

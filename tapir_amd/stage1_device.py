@@ -1,0 +1,201 @@
+"""Device-resident optimiser for the 202 constrained models of HyPhy's stage 1 (models_and_rates.bf:542-661).
+
+`tapir_amd/stage1.py` fits them with a batched L-BFGS written in numpy; on batches of many short loci (C2 / C4 shapes:
+10^5 small problems per block of loci) the numpy bookkeeping, not the likelihood kernel, was 70 % of the stage.  This
+module keeps the optimiser's whole state on the GPU -- torch tensors as device memory, `tphip_locus_loglik_dev` for the
+likelihoods, no host round trip per likelihood call -- and replaces the limited-memory update by what problems of at
+most four parameters allow: a dense BFGS matrix per problem, started from the metric of the quadratic screen
+(`Stage1._screen_submodels`), i.e. Newton-like steps from the first iteration.
+
+Same objective, same stencil gradients (central differences of the value kernel), same stopping, pruning and
+boundary-escape rules as `stage1._LBFGS` + `Stage1.fit_submodels`; the results agree with the numpy path within the
+stage's tolerance (tests/test_gpu_stage1.py::test_stage1_device_fitter_matches_host_fitter).
+"""
+import numpy as np
+
+from . import stage1 as _s1
+
+
+def available(plan):
+    """The device path needs the real engine (device-pointer likelihood entry) and torch with a GPU."""
+    if not hasattr(plan, "locus_loglik_dev"):
+        return False
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+class DeviceSubmodelFitter:
+    def __init__(self, plan, d_states_ptr, stash, w6, locus, cls, active, stencil, need, kk, h, device=0):
+        import torch
+        self.torch = torch
+        self.plan = plan
+        self.dev = torch.device("cuda", device)
+        self.d_states_ptr = int(d_states_ptr)
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt, device=self.dev)  # noqa: E731
+        self.stash = t(stash, torch.float64)                  # [L, nnodes]
+        self.w6 = t(w6, torch.float64)                        # [L, 6]
+        self.locus = t(locus, torch.int64)                    # [P]
+        self.cls = t(cls, torch.int64)                        # [P, 6], -1 = the class of AG
+        self.active = t(active, torch.bool)                   # [P, 4]
+        self.stencil = t(stencil, torch.float64)              # [P, 9, 6]
+        self.need = t(need, torch.bool)                       # [P, 9]
+        self.kk = t(kk, torch.float64)                        # [P]
+        self.h = float(h)
+        self.nevals = 0
+        self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+
+    # ---- likelihood -------------------------------------------------------------------------------------------
+    def _exch(self, x, idx):
+        r = self.torch.exp(x)
+        cls = self.cls[idx]
+        pick = self.torch.gather(r, 1, cls.clamp(min=0))
+        return self.torch.where(cls < 0, self.torch.ones_like(pick), pick)
+
+    def _lik(self, loc, exch):
+        """-lnL of candidates (locus loc[c], exchangeabilities exch[c]) at the stashed lengths / totalFactor(model)."""
+        torch = self.torch
+        n = loc.numel()
+        if n == 0:
+            return torch.zeros(0, dtype=torch.float64, device=self.dev)
+        scale = 1.0 / (exch * self.w6[loc]).sum(dim=1)
+        loc32 = loc.to(torch.int32).contiguous()
+        out = torch.empty(n, dtype=torch.float64, device=self.dev)
+        pidx = torch.full((n,), -1, dtype=torch.int32, device=self.dev)
+        pfac = torch.ones(n, dtype=torch.float64, device=self.dev)
+        self.plan.locus_loglik_dev(self.d_states_ptr, n, loc32, exch.contiguous(), self.stash, loc32, scale.contiguous(), pidx,
+                                   pfac, out, self.stream)
+        self.nevals += n
+        return -out
+
+    def value(self, x, idx):
+        return self._lik(self.locus[idx], self._exch(x, idx))
+
+    def value_and_grad(self, x, idx):
+        """Central differences on the 9-point stencil, skipping the points of inactive dimensions."""
+        torch = self.torch
+        n = idx.numel()
+        base = self._exch(x, idx)                                         # [n, 6]
+        need = self.need[idx]                                             # [n, 9]
+        row, pt = torch.nonzero(need, as_tuple=True)
+        exch = base[row] * self.stencil[idx[row], pt]                     # [m, 6]
+        fc = self._lik(self.locus[idx[row]], exch)
+        F = torch.zeros((n, 9), dtype=torch.float64, device=self.dev)
+        F[row, pt] = fc
+        g = (F[:, 1::2] - F[:, 2::2]) / (2.0 * self.h)
+        return F[:, 0], torch.where(self.active[idx], g, torch.zeros_like(g))
+
+    # ---- the optimiser ----------------------------------------------------------------------------------------
+    def run(self, x0, hdiag, best, maxit=100, ftol=1e-10, gtol=2e-6, ptol=1e-9, prune=True):
+        """x0 [P, 4] start (the screened optima), hdiag [P, 4] curvature of -lnL per parameter from the screen (NaN where
+        unknown), best [L] best Akaike score lnL - k seen per locus so far.  Returns (x [P, 4], f [P] = -lnL, iterations)."""
+        torch = self.torch
+        dev = self.dev
+        P = x0.shape[0]
+        x = torch.as_tensor(x0, dtype=torch.float64, device=dev).clone()
+        hd = torch.as_tensor(hdiag, dtype=torch.float64, device=dev)
+        best = torch.as_tensor(best, dtype=torch.float64, device=dev).clone()
+        lo, hi = _s1.LOG_RATE_MIN, _s1.LOG_RATE_MAX
+        all_idx = torch.arange(P, device=dev)
+        f, g = self.value_and_grad(x, all_idx)
+        # inverse metric: 1 / curvature on the diagonal where the screen supplied one, identity-scaled otherwise
+        inv = torch.where(torch.isfinite(hd) & (hd > 1e-12), 1.0 / hd.clamp(min=1e-12), torch.ones_like(hd))
+        Hinv = torch.diag_embed(inv)
+        converged = torch.zeros(P, dtype=torch.bool, device=dev)
+        last_df = torch.full((P,), float("inf"), dtype=torch.float64, device=dev)
+        kicks = torch.zeros(P, dtype=torch.int64, device=dev)
+        iters = torch.zeros(P, dtype=torch.int64, device=dev)
+        pruned = 0
+        for it in range(maxit):
+            live = torch.nonzero(~converged, as_tuple=True)[0]
+            if live.numel() == 0:
+                break
+            xl, fl, gl, Hl = x[live], f[live], g[live], Hinv[live]
+            d = -torch.bmm(Hl, gl.unsqueeze(2)).squeeze(2)
+            d = torch.where(self.active[live], d, torch.zeros_like(d)).clamp(-_s1.MAX_LOG_STEP, _s1.MAX_LOG_STEP)
+            gd = (gl * d).sum(dim=1)
+            bad = ~(gd < 0)
+            d = torch.where(bad.unsqueeze(1), -gl, d)
+            gd = torch.where(bad, -(gl * gl).sum(dim=1), gd)
+            scale_f = 1.0 + fl.abs()
+            gmax = gl.abs().max(dim=1).values
+            stop = (last_df[live] <= ftol * scale_f) & (-gd <= ptol * scale_f) & (gmax <= gtol * scale_f)
+            stop |= gmax <= 1e-9
+            if bool(stop.any()):
+                # boundary trap of the log scale (Stage1._sub_escape): a class rate sitting at its lower bound although the
+                # likelihood rises with the rate itself is put back at ESCAPE_RATE and the search continues from there
+                si = live[stop]
+                xs, gs = x[si], g[si]
+                slope = gs / torch.exp(xs)
+                fscale = (1.0 + f[si].abs()).unsqueeze(1)
+                kick = (xs < lo + 1.0) & self.active[si] & (slope * _s1.ESCAPE_RATE < -1e-7 * fscale) & (kicks[si] < 2).unsqueeze(1)
+                moved = kick.any(dim=1)
+                if bool(moved.any()):
+                    mi = si[moved]
+                    x[mi] = torch.where(kick[moved], torch.full_like(xs[moved], float(np.log(_s1.ESCAPE_RATE))), xs[moved])
+                    kicks[mi] += 1
+                    fm, gm = self.value_and_grad(x[mi], mi)
+                    f[mi], g[mi] = fm, gm
+                    Hinv[mi] = torch.diag_embed(inv[mi])
+                    last_df[mi] = float("inf")
+                    stop_idx = si[~moved]
+                    converged[stop_idx] = True
+                    continue
+                converged[si] = True
+                keep = ~stop
+                if not bool(keep.any()):
+                    continue
+                live, xl, fl, gl, Hl, d, gd = live[keep], xl[keep], fl[keep], gl[keep], Hl[keep], d[keep], gd[keep]
+            # line search: Armijo backtracking from the full quasi-Newton step
+            n = live.numel()
+            t = torch.minimum(torch.ones(n, dtype=torch.float64, device=dev),
+                              _s1.MAX_LOG_STEP / d.abs().max(dim=1).values.clamp(min=1e-300))
+            xnew, fnew = xl.clone(), fl.clone()
+            pending = torch.arange(n, device=dev)
+            for _ in range(30):
+                if pending.numel() == 0:
+                    break
+                xt = (xl[pending] + t[pending].unsqueeze(1) * d[pending]).clamp(lo, hi)
+                ft = self.value(xt, live[pending])
+                ok = (ft <= fl[pending] + 1e-4 * t[pending] * gd[pending]) & torch.isfinite(ft)
+                acc = pending[ok]
+                xnew[acc], fnew[acc] = xt[ok], ft[ok]
+                pending = pending[~ok]
+                t[pending] = t[pending] * 0.5
+            failed = torch.zeros(n, dtype=torch.bool, device=dev)
+            failed[pending] = True
+            fx, gx = self.value_and_grad(xnew, live)
+            # dense BFGS update of the inverse metric (problems of <= 4 parameters)
+            s_ = xnew - xl
+            y_ = gx - gl
+            sy = (s_ * y_).sum(dim=1)
+            upd = (sy > 1e-12 * torch.sqrt((s_ * s_).sum(dim=1) * (y_ * y_).sum(dim=1) + 1e-300)) & ~failed
+            rho = torch.where(upd, 1.0 / torch.where(upd, sy, torch.ones_like(sy)), torch.zeros_like(sy))
+            Hy = torch.bmm(Hl, y_.unsqueeze(2)).squeeze(2)
+            yHy = (y_ * Hy).sum(dim=1)
+            r1 = rho.unsqueeze(1).unsqueeze(2)
+            term = (1.0 + rho * yHy).unsqueeze(1).unsqueeze(2) * r1 * (s_.unsqueeze(2) * s_.unsqueeze(1)) \
+                - r1 * (Hy.unsqueeze(2) * s_.unsqueeze(1) + s_.unsqueeze(2) * Hy.unsqueeze(1))
+            Hinv[live] = torch.where(upd.unsqueeze(1).unsqueeze(2), Hl + term, Hl)
+            df = fl - fx
+            last_df[live] = torch.where(failed, torch.zeros_like(df), df)
+            # a failed line search with a learned metric: fall back to the screen's metric once before giving up
+            learned = (Hl - torch.diag_embed(inv[live])).abs().amax(dim=(1, 2)) > 0
+            retry = failed & learned
+            Hinv[live[retry]] = torch.diag_embed(inv[live[retry]])
+            last_df[live[retry]] = float("inf")
+            done = failed & ~retry
+            if prune:
+                score = -fx - self.kk[live]
+                loc = self.locus[live]
+                best = best.scatter_reduce(0, loc, score, reduce="amax", include_self=True)
+                drop = score + 3.0 * df.clamp(min=0.0) < best[loc] - _s1.PRUNE_NATS
+                pruned += int(drop.sum())
+                done = done | drop
+            x[live], f[live], g[live] = xnew, fx, gx
+            iters[live] += 1
+            converged[live[done]] = True
+        self.pruned = pruned
+        return x.cpu().numpy(), f.cpu().numpy(), iters.cpu().numpy()

@@ -142,6 +142,36 @@ def test_stage1_on_the_bundled_locus_vs_restatement_and_phydesign():
     assert np.max(np.abs(got[0] - want) / want) < 0.06
 
 
+def test_stage1_device_fitter_matches_host_fitter():
+    """The constrained models are fitted by the device-resident optimiser (tapir_amd/stage1_device.py: state in HBM, dense
+    BFGS per problem, no host round trip per likelihood call) by default; the numpy L-BFGS of stage1.py is the same
+    computation on the host.  Both must reach the same optima: averaged rates 1e-5, weights 1e-6, lnL of every model that
+    carries weight 1e-5 -- on short loci (many models matter) and on long ones (a handful)."""
+    engine = _engine()
+    from tapir_amd import stage1, synth
+    for L, n, nt, seed in ((12, 300, 10, 41), (3, 6000, 16, 42)):
+        d = synth.simulate(L, n, nt, seed)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        st = d["states"].numpy()
+        pi = np.asarray(d["pi"])
+        blen = np.asarray(pin["blen"]) / pin["correction"]
+        plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"],
+                           [1], [[0, 1]], correction=pin["correction"])
+        s_dev = stage1.Stage1(plan, st, pi, pin["parent"], blen)
+        a = s_dev.run()
+        assert s_dev.sub_device, "the device fitter did not run"
+        s_dev.close()
+        s_host = stage1.Stage1(plan, st, pi, pin["parent"], blen, device_fit=False)
+        b = s_host.run()
+        assert not s_host.sub_device
+        s_host.close()
+        plan.close()
+        assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-5
+        assert np.max(np.abs(a["weights"] - b["weights"])) < 1e-6
+        heavy = b["weights"] > 1e-8
+        assert np.max(np.abs(a["lnl"] - b["lnl"])[heavy]) < 1e-5
+
+
 def test_stage1_degenerate_loci_stay_finite():
     """Edge cases of the domain: an empty locus, a locus of gaps only, an invariant locus (nothing to estimate: every
     model fits equally, lengths collapse to the lower bound), one informative locus among them, and a 2-taxon tree.
