@@ -410,6 +410,8 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
             // fewer columns: 90 % up front there (C4: 9.0 vs 9.2-9.3 ms), 80 % when shares lie inside long loci (C3: 6.9 vs 7.0)
             const int64_t avg_locus = ncols / std::max<int64_t>(1, d->nloci);
             p->site_first_fraction = !uneven ? 0.0 : (share >= 2 * avg_locus ? 0.9 : 0.8);
+            // whole C5 with the spilled stack slot (8 waves per CU): (3, 0.8) 109.6 ms, (3, 0.9) 113.3, (4, 0.85) 109.1, (2, 0.8) 117.1
+            if (uneven && p->site_lds_depth < p->prog.stack_depth) p->site_first_fraction = 0.8;
             if (const char* e8 = getenv("TPHIP_SITE_FIRST_FRACTION")) p->site_first_fraction = atof(e8);
             if (const char* e7 = getenv("TPHIP_SITE_GRID_MULT")) { long v = atol(e7); if (v >= 1 && v <= 16) p->site_grid_mult = (int32_t)v; }
         }
