@@ -125,7 +125,8 @@ typedef struct tphip_plan_desc {
     /* HyPhy fits one rate per UNIQUE column pattern of a locus and reports it for every column that carries it
      * (bf:1033-1044: GetDataInfo(dupInfo...), alreadyDone[siteMap]).  TPHIP_DEDUP_AUTO does the same wherever a cheap
      * per-locus estimate says at least ~15 % of the columns that need the optimiser are repeats (real loci; the synthetic
-     * alignments with random gaps hardly repeat a column); ON / OFF force it.  The outputs are bit-identical either way. */
+     * alignments with random gaps hardly repeat a column), in batches of at least 2^20 columns (smaller ones are
+     * latency-bound: nothing to gain); ON / OFF force it.  The outputs are bit-identical either way. */
     int32_t pattern_dedup;     /* TPHIP_DEDUP_*                                                        */
 } tphip_plan_desc;
 

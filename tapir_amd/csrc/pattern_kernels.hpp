@@ -175,10 +175,16 @@ struct DedupParams {
 
 __device__ __forceinline__ unsigned long long dedup_key(uint64_t h) { return h == kDedupEmpty ? 0ull : h; }
 
-constexpr int kDedupEstimateBlock = 1024;
 constexpr int64_t kDedupEstimatePrefix = 16384;   // columns of a locus the estimate looks at (0.17 -> 0.02 ms on C3)
+// Batches below this many columns are not de-duplicated in automatic mode: they run in the latency-bound small-batch
+// mode of site_rate_kernel (one wave per locus slice), where fewer columns hardly shorten the kernel and the four extra
+// launches cost more than they save (C2, 5e5 columns: 0.50 -> 0.53 ms per step with the machinery idling).
+constexpr int64_t kDedupAutoMinColumns = 1 << 20;
 
-__global__ __launch_bounds__(kDedupEstimateBlock) void dedup_estimate_kernel(DedupParams P) {
+// kBlock: 1024 threads for long loci, 256 for short ones (1000 workgroups of 1024 threads in front of the one-wave
+// workgroups of site_rate_kernel made THAT kernel 24 % slower on C2 -- the effect round 1 saw with compact_kernel)
+template <int kBlock>
+__global__ __launch_bounds__(kBlock) void dedup_estimate_kernel(DedupParams P) {
     __shared__ unsigned bitmap[kDedupBitmapBits / 32];
     __shared__ int counts[2];
     const int locus = blockIdx.x;

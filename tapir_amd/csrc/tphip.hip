@@ -427,6 +427,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     if (const char* e9 = getenv("TPHIP_DEDUP")) {   // test/tuning knob: 0 = never, 1 = always, anything else = automatic
         p->dedup_mode = (e9[0] == '0') ? DEDUP_OFF : (e9[0] == '1') ? DEDUP_ON : DEDUP_AUTO;
     }
+    if (p->dedup_mode == DEDUP_AUTO && ncols < kDedupAutoMinColumns) p->dedup_mode = DEDUP_OFF;   // small batch: see pattern_kernels.hpp
     if (p->dedup_mode != DEDUP_OFF) {
         p->ws_hash = off; off = align_up(off + sizeof(uint64_t) * (size_t)ncols, 256);
         p->ws_dup_of = off; off = align_up(off + sizeof(int32_t) * (size_t)ncols, 256);
@@ -556,7 +557,8 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     if (p->n_pi_chunks > 0) {
         classify_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(kPiBlock), 0, st>>>(C);
         if (dedup) {   // one rate per unique site pattern (bf:1033-1044); loci that hardly repeat a column skip it
-            dedup_estimate_kernel<<<dim3((unsigned)p->nloci), dim3(kDedupEstimateBlock), 0, st>>>(D);
+            if (p->max_locus_cols > 2048) dedup_estimate_kernel<1024><<<dim3((unsigned)p->nloci), dim3(1024), 0, st>>>(D);
+            else dedup_estimate_kernel<256><<<dim3((unsigned)p->nloci), dim3(256), 0, st>>>(D);
             dedup_insert_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
             dedup_resolve_kernel<<<dim3((unsigned)p->n_pi_chunks), dim3(256), 0, st>>>(D);
         }

@@ -410,8 +410,8 @@ def test_stage2_pattern_dedup(chr1_918, monkeypatch):
         got, ev = runs[mode]
         for k in base:
             assert np.array_equal(got[k], base[k], equal_nan=True), (mode, k)
-        assert ev < 0.2 * ev_off, (mode, ev, ev_off)          # <= 57 patterns (fewer need the optimiser) of 2000 columns
-    assert runs[engine.DEDUP_ON][1] == runs[engine.DEDUP_AUTO][1]
+    assert runs[engine.DEDUP_ON][1] < 0.2 * ev_off            # <= 57 patterns (fewer need the optimiser) of 2000 columns
+    assert runs[engine.DEDUP_AUTO][1] == ev_off               # a batch this small is left alone in automatic mode
     # duplicates of one pattern carry one answer
     first = {}
     for col in range(S):
@@ -439,8 +439,27 @@ def test_stage2_pattern_dedup(chr1_918, monkeypatch):
             for k in outs[engine.DEDUP_OFF][0]:
                 assert np.array_equal(outs[mode][0][k], outs[engine.DEDUP_OFF][0][k], equal_nan=True), (ntaxa, mode, k)
         assert outs[engine.DEDUP_ON][1] < 0.8 * outs[engine.DEDUP_OFF][1]     # 2400 of 7200 columns collapse to <= 300
-        # automatic: on for the resampled loci only; the loci with random gaps hardly repeat a column
-        assert outs[engine.DEDUP_ON][1] <= outs[engine.DEDUP_AUTO][1] < 0.85 * outs[engine.DEDUP_OFF][1]
+        assert outs[engine.DEDUP_AUTO][1] == outs[engine.DEDUP_OFF][1]   # small batch: automatic mode stays off
+    # per-locus decision of the automatic mode (batches of >= 2^20 columns): 24 loci x 50 000 columns, every other locus a
+    # resample of its own first 500 columns -- those are de-duplicated, the loci with random gaps are not
+    d = synth.simulate(24, 500, 64, 45)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    src = d["states"].numpy()
+    fresh = synth.simulate(24, 50000, 64, 46, device="cuda", tree=(d["root"], d["names"]))["states"].cpu().numpy()
+    mix = np.concatenate([src[:, l * 500 + rng.integers(0, 500, 50000)] if l % 2 else fresh[:, l * 50000:(l + 1) * 50000]
+                          for l in range(24)], axis=1)
+    mix = np.ascontiguousarray(mix)
+    res = {}
+    for mode in (engine.DEDUP_OFF, engine.DEDUP_ON, engine.DEDUP_AUTO):
+        plan = engine.Plan(64, pin["parent"], pin["blen"], pin["leaf"], np.arange(25) * 50000, d["pi"], d["exch"], pin["T"], [10],
+                           [[5, 15]], correction=pin["correction"], pattern_dedup=mode)
+        res[mode] = (plan.run_fused(mix), plan.last_eval_count())
+        plan.close()
+    for mode in (engine.DEDUP_ON, engine.DEDUP_AUTO):
+        for k in res[engine.DEDUP_OFF][0]:
+            assert np.array_equal(res[mode][0][k], res[engine.DEDUP_OFF][0][k], equal_nan=True), (mode, k)
+    assert res[engine.DEDUP_AUTO][1] < 0.6 * res[engine.DEDUP_OFF][1]          # the resampled half collapses
+    assert res[engine.DEDUP_ON][1] <= res[engine.DEDUP_AUTO][1] <= 1.05 * res[engine.DEDUP_ON][1]
     # synthetic batch without repeats: automatic mode leaves it alone (same evaluations as off)
     d = synth.simulate(4, 3000, 64, 43)
     pin = synth.plan_inputs(d["root"], d["names"])
