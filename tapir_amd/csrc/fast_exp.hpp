@@ -62,19 +62,23 @@ __device__ __constant__ const double kExp2Table[64] = {
 // Table-driven exp(x), x <= 0 (Tang 1989 with a 64-entry table): x = (64 n + j) ln2/64 + r, |r| <= ln2/128,
 // exp(x) = 2^n * T[j] * (1 + q(r)), q of degree 5 (truncation r^6/720 < 4e-17).  11 FP64 ops + one LDS read
 // instead of 19 FP64 ops; error <= 1.5 ulp.
-__device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ etab) {
+// c4: the polynomial's coefficient 1/24 held in a VGPR by the caller.  fma(r, 1/120, 1/24) has two constant operands and a
+// VOP3 instruction takes one from the scalar side, so the compiler re-materialised the other with a v_mov_b64 in front of
+// every exp (3 per tree op); a register the compiler cannot see through (empty asm, see site_rate_kernel) stays put.
+__device__ __forceinline__ double exp_nonpos_tab(double x, const double* __restrict__ etab, double c4 = 4.1666666666666664e-02) {
     const double INV = 92.33248261689366;           // 64 / ln2
     const double L_HI = 0.01083042469326756;        // ln2/64, 32 significant bits: k*L_HI is exact for |k| < 2^20
     const double L_LO = 2.9815858269852933e-12;
     const double SHIFT = 6755399441055744.0;        // 1.5 * 2^52
-    x = fmax(x, -708.0);
+    // (no clamp at -708: 2^n is applied with ldexp, which underflows to 0 by itself, and the shift trick holds for
+    //  |x| < 2^24 / INV * 2^7 -- site rates stop at s = 1e4, so |x| = |lambda t s| stays below ~1e5)
     const double t = fma(x, INV, SHIFT);            // low 32 bits of t = k = 64 n + j
     const double kd = t - SHIFT;
     double r = fma(-kd, L_HI, x);
     r = fma(-kd, L_LO, r);
     const int k = (int)(unsigned)__double_as_longlong(t);
     const double T = etab[k & 63];
-    double q = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);
+    double q = fma(r, 8.333333333333333e-03, c4);
     q = fma(q, r, 1.6666666666666666e-01);
     q = fma(q, r, 0.5);
     q = fma(q, r, 1.0);

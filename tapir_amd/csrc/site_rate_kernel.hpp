@@ -77,6 +77,7 @@ __device__ __forceinline__ void partial_mul(Partial& a, const Partial& m) {
 // The locus' model as plain scalars (wave-uniform: the compiler keeps them in SGPRs).
 struct ModelRegs {
     double lam[3], U[12], Ui[12], pi[4];
+    double c4;   // 1/24 for exp_nonpos_tab, pinned to a VGPR (see fast_exp.hpp)
 };
 
 // The 31 doubles go through LDS so that they land in VGPRs (replicated across lanes): 62 SGPRs of model
@@ -92,6 +93,8 @@ __device__ __forceinline__ ModelRegs load_model(const LocusModel* __restrict__ M
     for (int i = 0; i < 12; ++i) { R.U[i] = mtab[3 + i]; R.Ui[i] = mtab[15 + i]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) R.pi[i] = mtab[27 + i];
+    R.c4 = 4.1666666666666664e-02;
+    asm volatile("" : "+v"(R.c4));   // opaque: the compiler keeps it in its register instead of re-creating the constant
     return R;
 }
 
@@ -102,7 +105,7 @@ __device__ __forceinline__ void tip_message(const ModelRegs& R, const double* __
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         double x = R.lam[k] * ts;
-        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
+        double e = kUseExpTable ? exp_nonpos_tab(x, etab, R.c4) : exp_nonpos(x);
         a[k] = e * w[k + 1];
         b[k] = x * a[k];
         c[k] = fma(x, b[k], b[k]);
@@ -140,7 +143,7 @@ __device__ __forceinline__ void tip_message_over(const ModelRegs& R, const doubl
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         double x = R.lam[k] * ts;
-        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
+        double e = kUseExpTable ? exp_nonpos_tab(x, etab, R.c4) : exp_nonpos(x);
         a[k] = e * w[k + 1];
         b[k] = x * a[k];
         c[k] = fma(x, b[k], b[k]);
@@ -156,7 +159,7 @@ __device__ __forceinline__ void cherry_over(const ModelRegs& R, const double* __
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         x[k] = R.lam[k] * ts;
-        e[k] = kUseExpTable ? exp_nonpos_tab(x[k], etab) : exp_nonpos(x[k]);
+        e[k] = kUseExpTable ? exp_nonpos_tab(x[k], etab, R.c4) : exp_nonpos(x[k]);
         a[k] = e[k] * w1[k + 1];
         b[k] = x[k] * a[k];
         c[k] = fma(x[k], b[k], b[k]);
@@ -197,7 +200,7 @@ __device__ __forceinline__ void branch_apply(const ModelRegs& R, const double* _
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         double x = R.lam[k] * ts;
-        double e = kUseExpTable ? exp_nonpos_tab(x, etab) : exp_nonpos(x);
+        double e = kUseExpTable ? exp_nonpos_tab(x, etab, R.c4) : exp_nonpos(x);
         a[k] = e * w0[k + 1];
         double ew1 = e * w1[k + 1], ew2 = e * w2[k + 1];
         b[k] = fma(x, a[k], ew1);

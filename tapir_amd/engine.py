@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtphip.so")
+# TPHIP_LIB: another build of the library (same-box A/B comparisons of kernel variants, tools/ only)
+LIB_PATH = os.environ.get("TPHIP_LIB") or os.path.join(_HERE, "libtphip.so")
 
 FLAG_OK, FLAG_FLAT, FLAG_SATURATED, FLAG_ZERO, FLAG_MAXIT = 0, 1, 2, 3, 4
 START_PARSIMONY, START_REFERENCE = 0, 1
