@@ -339,6 +339,14 @@ class Plan:
                                                 _ptr(d_blen_vecs), _ptr(d_cand_vec), _ptr(d_cand_scale), _ptr(d_cand_pidx),
                                                 _ptr(d_cand_pfac), _ptr(d_out), stream))
 
+    def locus_gradient_dev(self, d_states_ptr, ncand, d_cand_locus, d_cand_exch, d_blen_vecs, d_cand_vec, d_cand_scale,
+                           d_cand_pidx, d_cand_pfac, d_lnl, d_dexch, d_dlogt, d_sum_dlogt, d_d2logt, stream=0):
+        """tphip_locus_gradient_dev on device tensors (d_dlogt / d_d2logt may be None); nothing is copied or synchronised."""
+        _check(self._lib.tphip_locus_gradient_dev(self._h, d_states_ptr, int(ncand), _ptr(d_cand_locus), _ptr(d_cand_exch),
+                                                  _ptr(d_blen_vecs), _ptr(d_cand_vec), _ptr(d_cand_scale), _ptr(d_cand_pidx),
+                                                  _ptr(d_cand_pfac), _ptr(d_lnl), _ptr(d_dexch), _ptr(d_dlogt),
+                                                  _ptr(d_sum_dlogt), _ptr(d_d2logt), stream))
+
     def locus_gradient(self, states, blen_vecs, cand_locus, cand_exch, cand_vec=None, cand_scale=None, cand_pidx=None,
                        cand_pfac=None, cache=None, per_branch=True, curvature=False):
         """locus_loglik plus its derivatives (tphip_locus_gradient): returns (lnl[n], dexch[n, 6], dlogt[n, nnodes] or

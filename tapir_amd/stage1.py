@@ -254,6 +254,7 @@ class Stage1:
         self.screen_models = screen_models   # quadratic screen of the 202 constrained models (see _screen_submodels)
         self.device_fit = device_fit         # fit the surviving models with the device-resident optimiser (stage1_device.py)
         self.sub_device = False
+        self.grm_device = False
         self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
         self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
         self.pi = self.pi / self.pi.sum(1, keepdims=True)
@@ -418,10 +419,19 @@ class Stage1:
         lo = np.concatenate([np.full(5, LOG_RATE_MIN), np.full(len(self.branches), LOG_BLEN_MIN)])
         hi = np.concatenate([np.full(5, LOG_RATE_MAX), np.full(len(self.branches), LOG_BLEN_MAX)])
         self._kicks = np.zeros(L, dtype=np.int64)
-        opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi,
-                     escape=self._grm_escape if self.analytic else None)
-        x, f = opt.run()
-        self.grm_iters = opt.iters
+        from . import stage1_device
+        if self.device_fit and self.analytic and self.precondition and stage1_device.available(self.plan) and self.cache.ptr:
+            # L-BFGS state on the GPU (stage1_device.DeviceLBFGS): same iteration, no numpy in the loop
+            fit = stage1_device.DeviceGrmFitter(self.plan, self.cache.ptr.value, self.pi, self.branches, self.nn, device=self.plan.device)
+            x, f, self.grm_iters = fit.fit(x0, lo, hi, maxit)
+            self.nevals += fit.nevals
+            self.ngrads += fit.ngrads
+            self.grm_device = True
+        else:
+            opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi,
+                         escape=self._grm_escape if self.analytic else None)
+            x, f = opt.run()
+            self.grm_iters = opt.iters
         exch = self._exch_from_free(x[:, :5])
         t = np.zeros((L, self.nn))
         t[:, self.branches] = np.exp(x[:, 5:]) / total_factor(self.pi, exch)[:, None]

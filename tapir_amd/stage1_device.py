@@ -199,3 +199,244 @@ class DeviceSubmodelFitter:
             converged[live[done]] = True
         self.pruned = pruned
         return x.cpu().numpy(), f.cpu().numpy(), iters.cpu().numpy()
+
+
+# ---- the general reversible model (bf:487-520): 5 rates + every branch length ------------------------------------------
+class DeviceLBFGS:
+    """`stage1._LBFGS` with its state in HBM: the same batched L-BFGS (two-loop recursion over a ring of correction pairs
+    shared by all problems, diagonal initial metric from the objective's curvature, Armijo backtracking, the same stopping,
+    retry and escape rules), torch tensors instead of numpy arrays.  On 4000 loci x 131 parameters the numpy two-loop
+    recursion alone was 16 ms per iteration -- more than the kernels."""
+
+    def __init__(self, torch, value, value_and_grad, x0, history=8, maxit=200, ftol=1e-10, gtol=2e-6, ptol=1e-9, lo=None, hi=None,
+                 escape=None):
+        self.torch = torch
+        self.value, self.vg, self.escape = value, value_and_grad, escape
+        self.x = x0.clone()
+        self.m, self.maxit, self.ftol, self.gtol, self.ptol = history, maxit, ftol, gtol, ptol
+        self.lo, self.hi = lo, hi
+
+    def run(self):
+        torch = self.torch
+        x = self.x
+        P, D = x.shape
+        dev = x.device
+        f64 = torch.float64
+        live = torch.arange(P, device=dev)
+        f, g, hd = self.vg(x, live)
+        hdiag = hd.clone() if hd is not None else torch.full((P, D), float("nan"), dtype=f64, device=dev)
+        m = self.m
+        S = torch.zeros((m, P, D), dtype=f64, device=dev)
+        Y = torch.zeros((m, P, D), dtype=f64, device=dev)
+        rho = torch.zeros((m, P), dtype=f64, device=dev)
+        gamma_all = torch.ones(P, dtype=f64, device=dev)
+        nhist = torch.zeros(P, dtype=torch.int64, device=dev)
+        converged = torch.zeros(P, dtype=torch.bool, device=dev)
+        last_df = torch.full((P,), float("inf"), dtype=f64, device=dev)
+        fresh = torch.zeros(P, dtype=torch.bool, device=dev)
+        iters = torch.zeros(P, dtype=torch.int64, device=dev)
+        MAXS = _s1.MAX_LOG_STEP
+        for it in range(self.maxit):
+            live = torch.nonzero(~converged, as_tuple=True)[0]
+            if live.numel() == 0:
+                break
+            xl, fl, gl = x[live], f[live], g[live]
+            slots = [(it - 1 - j) % m for j in range(min(it, m))]
+            q = gl.clone()
+            alpha = {}
+            for i in slots:
+                a = rho[i, live] * (S[i, live] * q).sum(dim=1)
+                alpha[i] = a
+                q = q - a.unsqueeze(1) * Y[i, live]
+            gamma = gamma_all[live]
+            hl = hdiag[live]
+            okh = torch.isfinite(hl) & (hl > 1e-12)
+            have_h = torch.isfinite(hl).any(dim=1)
+            r = torch.where(okh, 1.0 / torch.where(okh, hl, torch.ones_like(hl)), gamma.unsqueeze(1).expand_as(hl)) * q
+            for i in reversed(slots):
+                bcoef = rho[i, live] * (Y[i, live] * r).sum(dim=1)
+                r = r + (alpha[i] - bcoef).unsqueeze(1) * S[i, live]
+            d = (-r).clamp(-MAXS, MAXS)
+            gd = (gl * d).sum(dim=1)
+            bad = ~(gd < 0)
+            d = torch.where(bad.unsqueeze(1), -gl, d)
+            gd = torch.where(bad, -(gl * gl).sum(dim=1), gd)
+            scale_f = 1.0 + fl.abs()
+            gmax = gl.abs().max(dim=1).values
+            stop = (last_df[live] <= self.ftol * scale_f) & (-gd <= self.ptol * scale_f) & (gmax <= self.gtol * scale_f)
+            stop |= gmax <= 1e-9
+            any_stop = bool(stop.any())
+            if any_stop and self.escape is not None:
+                si = live[stop]
+                xs, moved = self.escape(si, xl[stop], gl[stop])
+                if bool(moved.any()):
+                    mi = si[moved]
+                    x[mi] = xs[moved]
+                    fm, gm, hm = self.vg(x[mi], mi)
+                    f[mi], g[mi] = fm, gm
+                    if hm is not None:
+                        hdiag[mi] = hm
+                    rho[:, mi] = 0.0
+                    nhist[mi] = 0
+                    last_df[mi] = float("inf")
+                    continue
+            if any_stop:
+                converged[live[stop]] = True
+                keep = ~stop
+                if not bool(keep.any()):
+                    continue
+                live = live[keep]
+                xl, fl, gl, d, gd, hl, have_h, gamma = xl[keep], fl[keep], gl[keep], d[keep], gd[keep], hl[keep], have_h[keep], gamma[keep]
+            n = live.numel()
+            step0 = torch.where((nhist[live] == 0) & ~have_h,
+                                torch.minimum(torch.ones(n, dtype=f64, device=dev), 1.0 / gl.abs().max(dim=1).values.clamp(min=1e-300)),
+                                torch.ones(n, dtype=f64, device=dev))
+            dmax = d.abs().max(dim=1).values
+            t = torch.minimum(step0, MAXS / dmax.clamp(min=1e-300))
+            xnew, fnew = xl.clone(), fl.clone()
+            pending = torch.arange(n, device=dev)
+            for _ in range(30):
+                if pending.numel() == 0:
+                    break
+                xt = xl[pending] + t[pending].unsqueeze(1) * d[pending]
+                xt = torch.maximum(torch.minimum(xt, self.hi), self.lo)
+                ft = self.value(xt, live[pending])
+                ok = (ft <= fl[pending] + 1e-4 * t[pending] * gd[pending]) & torch.isfinite(ft)
+                acc = pending[ok]
+                xnew[acc], fnew[acc] = xt[ok], ft[ok]
+                pending = pending[~ok]
+                t[pending] = t[pending] * 0.5
+            failed = torch.zeros(n, dtype=torch.bool, device=dev)
+            failed[pending] = True
+            fx, gx, hx = self.vg(xnew, live)
+            if hx is not None:
+                hdiag[live] = hx
+            s_ = xnew - xl
+            y_ = gx - gl
+            sy = (s_ * y_).sum(dim=1)
+            yy = (y_ * y_).sum(dim=1)
+            upd = (sy > 1e-12 * torch.sqrt((s_ * s_).sum(dim=1) * yy + 1e-300)) & ~failed
+            slot = it % m
+            rho[slot] = 0.0
+            S[slot, live] = s_
+            Y[slot, live] = y_
+            rho[slot, live] = torch.where(upd, 1.0 / torch.where(upd, sy, torch.ones_like(sy)), torch.zeros_like(sy))
+            gamma_all[live] = torch.where(upd, sy / yy.clamp(min=1e-300), gamma)
+            nhist[live] += upd.to(torch.int64)
+            df = fl - fx
+            last_df[live] = torch.where(failed, torch.zeros_like(df), df)
+            retry = failed & (nhist[live] > 0)
+            ri = live[retry]
+            rho[:, ri] = 0.0
+            nhist[ri] = 0
+            last_df[ri] = float("inf")
+            done = (failed & ~retry & fresh[live]) | (failed & ~retry & (nhist[live] == 0))
+            fresh[live] = retry
+            x[live], f[live], g[live] = xnew, fx, gx
+            iters[live] += 1
+            converged[live[done]] = True
+        self.iters = iters
+        return x, f
+
+
+class DeviceGrmFitter:
+    """Objective of the general model on the device: coordinates (log rates [5], log b [branches]) with b = t * totalFactor(r)
+    the branch lengths in expected substitutions (stage1.Stage1._grm_point), value from `tphip_locus_loglik_dev`, value +
+    gradient + curvature of the branch lengths from `tphip_locus_gradient_dev`, chain rule and boundary escape as in
+    stage1.py (`_grm_value_and_grad`, `_grm_escape`)."""
+
+    def __init__(self, plan, d_states_ptr, pi, branches, nn, device=0):
+        import torch
+        self.torch = torch
+        self.plan = plan
+        self.dev = torch.device("cuda", device)
+        self.d_states_ptr = int(d_states_ptr)
+        self.pi = torch.as_tensor(np.ascontiguousarray(pi), dtype=torch.float64, device=self.dev)       # [L, 4]
+        self.branches = torch.as_tensor(np.ascontiguousarray(branches), dtype=torch.int64, device=self.dev)
+        self.nn = int(nn)
+        self.dk = torch.stack([2.0 * self.pi[:, i] * self.pi[:, j] for i, j in _s1._PAIRS], dim=1)       # [L, 6]
+        self.free = torch.tensor([0, 2, 3, 4, 5], dtype=torch.int64, device=self.dev)
+        L = self.pi.shape[0]
+        self.kicks = torch.zeros(L, dtype=torch.int64, device=self.dev)
+        self.last_f = torch.zeros(L, dtype=torch.float64, device=self.dev)
+        self.nevals = 0
+        self.ngrads = 0
+        self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _point(self, X, idx):
+        torch = self.torch
+        n = X.shape[0]
+        r = torch.exp(X[:, :5])
+        exch = torch.ones((n, 6), dtype=torch.float64, device=self.dev)
+        exch[:, self.free] = r
+        scale = 1.0 / (exch * self.dk[idx]).sum(dim=1)
+        vecs = torch.zeros((n, self.nn), dtype=torch.float64, device=self.dev)
+        vecs[:, self.branches] = torch.exp(X[:, 5:])
+        return exch, scale, vecs
+
+    def _cand(self, idx, n):
+        torch = self.torch
+        return (idx.to(torch.int32).contiguous(), torch.arange(n, dtype=torch.int32, device=self.dev),
+                torch.full((n,), -1, dtype=torch.int32, device=self.dev), torch.ones(n, dtype=torch.float64, device=self.dev))
+
+    def value(self, X, idx):
+        torch = self.torch
+        n = X.shape[0]
+        if n == 0:
+            return torch.zeros(0, dtype=torch.float64, device=self.dev)
+        exch, scale, vecs = self._point(X, idx)
+        loc, vec, pidx, pfac = self._cand(idx, n)
+        out = torch.empty(n, dtype=torch.float64, device=self.dev)
+        self.plan.locus_loglik_dev(self.d_states_ptr, n, loc, exch, vecs, vec, scale.contiguous(), pidx, pfac, out, self.stream)
+        self.nevals += n
+        return -out
+
+    def value_and_grad(self, X, idx):
+        torch = self.torch
+        n, D = X.shape
+        exch, scale, vecs = self._point(X, idx)
+        loc, vec, pidx, pfac = self._cand(idx, n)
+        lnl = torch.empty(n, dtype=torch.float64, device=self.dev)
+        dex = torch.empty((n, 6), dtype=torch.float64, device=self.dev)
+        dlt = torch.empty((n, self.nn), dtype=torch.float64, device=self.dev)
+        sdl = torch.empty(n, dtype=torch.float64, device=self.dev)
+        d2 = torch.empty((n, self.nn), dtype=torch.float64, device=self.dev)
+        self.plan.locus_gradient_dev(self.d_states_ptr, n, loc, exch, vecs, vec, scale.contiguous(), pidx, pfac, lnl, dex, dlt, sdl,
+                                     d2, self.stream)
+        self.nevals += n
+        self.ngrads += n
+        self.last_f[idx] = -lnl
+        # t_b = b_b / totalFactor(r): d log t_b / d r_q = -(2 pi_i pi_j) / totalFactor for every branch
+        dr = (dex - sdl.unsqueeze(1) * self.dk[idx] * scale.unsqueeze(1)) * exch        # d lnL / d log r_q at fixed b
+        g = torch.empty((n, D), dtype=torch.float64, device=self.dev)
+        g[:, :5] = dr[:, self.free]
+        g[:, 5:] = dlt[:, self.branches]
+        h = torch.full((n, D), float("nan"), dtype=torch.float64, device=self.dev)
+        h[:, 5:] = -d2[:, self.branches]
+        return -lnl, -g, h
+
+    def escape(self, idx, X, G):
+        """stage1.Stage1._grm_escape: collapsed branches (and rates at their lower bound) are tested in the original
+        parametrisation at a would-be stopping point and put back if the likelihood wants them longer."""
+        torch = self.torch
+        Xn = X.clone()
+        logb = X[:, 5:]
+        b = torch.exp(logb)
+        slope = G[:, 5:] / b
+        fscale = (1.0 + self.last_f[idx].abs()).unsqueeze(1)
+        few = (self.kicks[idx] < 3).unsqueeze(1)
+        kick = (b < 1e-6) & (slope * _s1.ESCAPE_LENGTH < -1e-7 * fscale) & few
+        Xn[:, 5:] = torch.where(kick, torch.full_like(logb, float(np.log(_s1.ESCAPE_LENGTH))), logb)
+        rslope = G[:, :5] / torch.exp(X[:, :5])
+        rkick = (X[:, :5] < _s1.LOG_RATE_MIN + 1.0) & (rslope * _s1.ESCAPE_RATE < -1e-7 * fscale) & few
+        Xn[:, :5] = torch.where(rkick, torch.full_like(X[:, :5], float(np.log(_s1.ESCAPE_RATE))), X[:, :5])
+        moved = kick.any(dim=1) | rkick.any(dim=1)
+        self.kicks[idx] += moved.to(torch.int64)
+        return Xn, moved
+
+    def fit(self, x0, lo, hi, maxit):
+        torch = self.torch
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=self.dev)  # noqa: E731
+        opt = DeviceLBFGS(torch, self.value, self.value_and_grad, t(x0), maxit=maxit, lo=t(lo), hi=t(hi), escape=self.escape)
+        x, f = opt.run()
+        return x.cpu().numpy(), f.cpu().numpy(), opt.iters.cpu().numpy()
