@@ -36,6 +36,7 @@ LOG_BLEN_MIN, LOG_BLEN_MAX = -23.0, 4.0     # branch lengths within [1e-10, 55]
 MAX_LOG_STEP = 2.0                          # largest move of a log-parameter in one iteration
 ESCAPE_RATE = 0.05                          # where a wrongly collapsed exchangeability is put back (Stage1._sub_escape)
 ESCAPE_LENGTH = 1e-3                        # where a wrongly collapsed branch is put back (Stage1._grm_escape)
+DEVICE_GRM_MIN_SIZE = 250000                # loci x parameters from which the general model is fitted by the device L-BFGS
 PRUNE_NATS = 21.0                           # see Stage1.fit_submodels: a model this far behind weighs < e^-21 = 8e-10
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
 
@@ -420,8 +421,11 @@ class Stage1:
         hi = np.concatenate([np.full(5, LOG_RATE_MAX), np.full(len(self.branches), LOG_BLEN_MAX)])
         self._kicks = np.zeros(L, dtype=np.int64)
         from . import stage1_device
-        if self.device_fit and self.analytic and self.precondition and stage1_device.available(self.plan) and self.cache.ptr:
-            # L-BFGS state on the GPU (stage1_device.DeviceLBFGS): same iteration, no numpy in the loop
+        big = x0.size >= DEVICE_GRM_MIN_SIZE or self.device_fit == "always"
+        if self.device_fit and big and self.analytic and self.precondition and stage1_device.available(self.plan) and self.cache.ptr:
+            # L-BFGS state on the GPU (stage1_device.DeviceLBFGS): same iteration, no numpy in the loop.  Only for large
+            # batches: an iteration is ~100 small torch launches (~7 ms), numpy's is cheaper below ~2000 loci x 131
+            # parameters (measured: 2000 x 1000 x 64 taxa 1.69 -> 1.35 s, but C2 shape 0.14 -> 0.46 s, 32 x 50 000 0.30 -> 0.53 s)
             fit = stage1_device.DeviceGrmFitter(self.plan, self.cache.ptr.value, self.pi, self.branches, self.nn, device=self.plan.device)
             x, f, self.grm_iters = fit.fit(x0, lo, hi, maxit)
             self.nevals += fit.nevals

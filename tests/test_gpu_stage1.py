@@ -157,13 +157,13 @@ def test_stage1_device_fitter_matches_host_fitter():
         blen = np.asarray(pin["blen"]) / pin["correction"]
         plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"],
                            [1], [[0, 1]], correction=pin["correction"])
-        s_dev = stage1.Stage1(plan, st, pi, pin["parent"], blen)
+        s_dev = stage1.Stage1(plan, st, pi, pin["parent"], blen, device_fit="always")   # general model on the device too
         a = s_dev.run()
-        assert s_dev.sub_device, "the device fitter did not run"
+        assert s_dev.sub_device and s_dev.grm_device, "the device fitters did not run"
         s_dev.close()
         s_host = stage1.Stage1(plan, st, pi, pin["parent"], blen, device_fit=False)
         b = s_host.run()
-        assert not s_host.sub_device
+        assert not s_host.sub_device and not s_host.grm_device
         s_host.close()
         plan.close()
         assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-5
