@@ -143,7 +143,8 @@ def _shared_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
 
-STAGE1_BLOCK_LOCI = 512   # loci fitted together: 512 x 202 models x 9-point stencils = 0.9 M candidates per call
+STAGE1_BLOCK_LOCI = 2048   # loci fitted together (bounds host memory: 2048 x 202 models x 9-point stencils = 3.7 M candidates at most;
+                           # large enough for the device-resident optimisers of stage1_device.py and to amortise straggler loci)
 
 
 def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, blen, leaf, T, times, intervals,
