@@ -36,6 +36,10 @@ tmp = tempfile.mkdtemp(dir="/dev/shm" if shm_ok else None)
 try:
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "--generate", tmp, str(nloci), str(ncols), str(ntaxa)])
     from tapir_amd import cli
+    try:
+        import torch  # noqa: F401  (stage 1's device-resident optimisers import it lazily: on a fresh box the first import pages
+    except ImportError:              #  the wheel in for ~10 s, which is the machine's cost, not the pipeline's; importing does not touch the GPU)
+        pass
     out = os.path.join(tmp, "out")
     os.mkdir(out)
     extra = [a for a in sys.argv[4:] if a != "--model-averaging"]
