@@ -24,6 +24,7 @@ constexpr int kPiBlock = 256;
 constexpr int kPiColsPerThread = 4;
 constexpr int kPiChunk = kPiBlock * kPiColsPerThread;  // 1024 columns per workgroup
 constexpr int kTimeTile = 16;
+constexpr int kIvTile = 8;      // intervals per register tile of pi_partial_kernel (2 * kIvTile <= kTimeTile rows of `red`)
 
 struct ClassifyParams {
     const uint8_t* states;
@@ -446,28 +447,56 @@ __global__ __launch_bounds__(kPiBlock) void pi_partial_kernel(PiParams P) {
         }
         __syncthreads();
     }
-    // ---- interval integrals
-    for (int k = 0; k < P.n_i; ++k) {
-        const double a = (double)P.intervals[2 * k], b = (double)P.intervals[2 * k + 1];
-        double si = 0.0, se = 0.0;
+    // ---- interval integrals, in tiles of kIvTile intervals: per column the first-panel exponentials of consecutive
+    // intervals of equal length are computed once (quadpack_device.hpp: GkFactors).  Per (thread, interval) the columns
+    // are still added in the order j = 0..3, then lanes, then waves: the sums keep their fixed order.
+    for (int k0 = 0; k0 < P.n_i; k0 += kIvTile) {
+        double si[kIvTile], se[kIvTile];
+#pragma unroll
+        for (int kk = 0; kk < kIvTile; ++kk) { si[kk] = 0.0; se[kk] = 0.0; }
 #pragma unroll 1
         for (int j = 0; j < kPiColsPerThread; ++j) {
             if (!ok[j]) continue;
-            double res, err = 0.0;
-            // (measured: the table-driven exp of fast_exp.hpp makes this kernel 1.65x SLOWER -- 84 scattered LDS
-            //  reads per column from one table shared by 256 threads -- so the quadrature keeps the library exp)
-            if (P.integ_mode == TPHIP_INTEG_QUADPACK) quad_townsend<false>(a, b, r[j], nullptr, res, err);
-            else res = integral_closed(a, b, r[j]);
-            si += res;
-            se += err;
+            GkFactors F;
+            double have_h = -1.0;        // half-length the factors in F were built for (intervals are wave-uniform)
+#pragma unroll
+            for (int kk = 0; kk < kIvTile; ++kk) {
+                const int k = k0 + kk;
+                if (k < P.n_i) {         // wave-uniform
+                    const double a = (double)P.intervals[2 * k], b = (double)P.intervals[2 * k + 1];
+                    double res, err = 0.0;
+                    // (measured: the table-driven exp of fast_exp.hpp makes this kernel 1.65x SLOWER -- scattered LDS reads
+                    //  from one table shared by 256 threads -- and its degree-13 polynomial 1.3x: the library exp stays)
+                    if (P.integ_mode == TPHIP_INTEG_QUADPACK) {
+                        const double hl = 0.5 * (b - a);
+                        if (4.0 * r[j] * hl < 30.0) {        // per lane: a huge rate takes the generic panel
+                            if (hl != have_h) { gk_factors(r[j], hl, F); have_h = hl; }
+                            quad_townsend_factored(a, b, r[j], F, res, err);
+                        } else {
+                            quad_townsend<false>(a, b, r[j], nullptr, res, err);
+                        }
+                    } else {
+                        res = integral_closed(a, b, r[j]);
+                    }
+                    si[kk] += res;
+                    se[kk] += err;
+                }
+            }
         }
-        si = wave_sum(si);
-        se = wave_sum(se);
-        if (lane == 0) { red[0][wave] = si; red[1][wave] = se; }
+#pragma unroll
+        for (int kk = 0; kk < kIvTile; ++kk) {
+            const int k = k0 + kk;
+            if (k < P.n_i) {
+                const double s1 = wave_sum(si[kk]), s2 = wave_sum(se[kk]);
+                if (lane == 0) { red[2 * kk][wave] = s1; red[2 * kk + 1][wave] = s2; }
+            }
+        }
         __syncthreads();
-        if (threadIdx.x < 2)
-            out[P.T + threadIdx.x * P.n_i + k] =
+        if (threadIdx.x < 2 * kIvTile && k0 + (int)(threadIdx.x >> 1) < P.n_i) {
+            const int kk = threadIdx.x >> 1, which = threadIdx.x & 1;
+            out[P.T + which * P.n_i + k0 + kk] =
                 ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+        }
         __syncthreads();
     }
 }

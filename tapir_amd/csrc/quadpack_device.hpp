@@ -99,6 +99,80 @@ __device__ __forceinline__ GK21 dqk21(double rate, double a, double b, const dou
     return o;
 }
 
+// The first panel of consecutive intervals of EQUAL length shares most of its exponentials: the 21 abscissae of [a, b] are
+// centr +- hlgth * xgk[j], so exp(-4 r t) = exp(-4 r centr) * exp(-/+ 4 r hlgth xgk[j]) and the second factor depends only
+// on the rate and the interval LENGTH (C5: 32 intervals of length 4; C2-C4: 4 of length 10).  GkFactors holds those ten
+// factors and their reciprocals for one (rate, length): 10 exps + 10 divisions once, then one exp (the centre) per
+// interval instead of 21.  Everything else is dqk21 above, operation for operation; an integrand value now carries two
+// more roundings (~1e-16 relative), far below the 1e-13 the integrals are checked to, and the error estimate of a smooth
+// panel is its 50 eps resabs floor either way.  Valid while exp(+4 r hlgth) cannot overflow or swamp: callers use it
+// for 4 r hlgth < 30 and the generic panel otherwise.
+struct GkFactors {
+    double fm[10];   // exp(-(4 r) * (hlgth * xgk[j])): multiplies exp(-4 r centr) at t = centr + absc_j
+    double fp[10];   // 1 / fm[j]:                                                  at t = centr - absc_j
+};
+
+__device__ __forceinline__ void gk_factors(double rate, double hlgth, GkFactors& F) {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+        const double absc = hlgth * kXgk[j];
+        F.fm[j] = exp(-(4.0 * rate * absc));
+        F.fp[j] = 1.0 / F.fm[j];
+    }
+}
+
+__device__ __forceinline__ GK21 dqk21_factored(double rate, double a, double b, const GkFactors& F) {
+#pragma clang fp contract(off)
+    const double epmach = DBL_EPSILON, uflow = DBL_MIN;
+    double fv1[10], fv2[10];
+    const double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    const double c16 = 16.0 * (rate * rate);
+    const double ec = exp(-(4.0 * rate * centr));
+    double resg = 0.0;
+    const double fc = c16 * centr * ec;
+    double resk = kWgk[10] * fc;
+    double resabs = fabs(resk);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int jtw = 2 * j + 1;
+        const double absc = hlgth * kXgk[jtw];
+        const double f1 = c16 * (centr - absc) * (ec * F.fp[jtw]), f2 = c16 * (centr + absc) * (ec * F.fm[jtw]);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        const double fsum = f1 + f2;
+        resg += kWg[j] * fsum;
+        resk += kWgk[jtw] * fsum;
+        resabs += kWgk[jtw] * (fabs(f1) + fabs(f2));
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int jtwm1 = 2 * j;
+        const double absc = hlgth * kXgk[jtwm1];
+        const double f1 = c16 * (centr - absc) * (ec * F.fp[jtwm1]), f2 = c16 * (centr + absc) * (ec * F.fm[jtwm1]);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        const double fsum = f1 + f2;
+        resk += kWgk[jtwm1] * fsum;
+        resabs += kWgk[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    const double reskh = resk * 0.5;
+    double resasc = kWgk[10] * fabs(fc - reskh);
+#pragma unroll
+    for (int j = 0; j < 10; ++j) resasc += kWgk[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    GK21 o;
+    o.result = resk * hlgth;
+    o.resabs = resabs * dhlgth;
+    o.resasc = resasc * dhlgth;
+    double abserr = fabs((resk - resg) * hlgth);
+    if (o.resasc != 0.0 && abserr != 0.0) {
+        const double q = 200.0 * abserr / o.resasc;
+        const double q15 = q * sqrt(q);  // q^1.5
+        abserr = o.resasc * fmin(1.0, q15);
+    }
+    if (o.resabs > uflow / (50.0 * epmach)) abserr = fmax((epmach * 50.0) * o.resabs, abserr);
+    o.abserr = abserr;
+    return o;
+}
+
 // QUADPACK dqpsrt (1-based lists as published)
 __device__ inline void dqpsrt(int limit, int last, int* maxerr, double* ermax, const double* elist, int* iord, int* nrmax) {
     if (last <= 2) {
@@ -348,6 +422,20 @@ __device__ __forceinline__ void quad_townsend(double a, double b, double rate, c
     const bool roundoff = (g.abserr <= 100.0 * epmach * g.resabs && g.abserr > errbnd);  // ier = 2
     const bool accept = roundoff || (g.abserr <= errbnd && g.abserr != g.resasc) || g.abserr == 0.0;
     if (!accept) dqagse_adaptive<TAB>(rate, a, b, g, etab, &result, &abserr);
+}
+
+// The same with the first panel's exponentials shared through F (= gk_factors(rate, (b - a) / 2)).
+__device__ __forceinline__ void quad_townsend_factored(double a, double b, double rate, const GkFactors& F, double& result,
+                                                       double& abserr) {
+#pragma clang fp contract(off)
+    const double epsabs = 1.49e-8, epsrel = 1.49e-8, epmach = DBL_EPSILON;
+    const GK21 g = dqk21_factored(rate, a, b, F);
+    result = g.result;
+    abserr = g.abserr;
+    const double errbnd = fmax(epsabs, epsrel * fabs(g.result));
+    const bool roundoff = (g.abserr <= 100.0 * epmach * g.resabs && g.abserr > errbnd);  // ier = 2
+    const bool accept = roundoff || (g.abserr <= errbnd && g.abserr != g.resasc) || g.abserr == 0.0;
+    if (!accept) dqagse_adaptive<false>(rate, a, b, g, nullptr, &result, &abserr);
 }
 
 // Closed form: int_a^b 16 r^2 t exp(-4 r t) dt = g(4rb) - g(4ra), g(x) = 1 - (1+x) exp(-x); series for small x.
