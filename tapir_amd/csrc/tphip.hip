@@ -13,6 +13,7 @@
 #include "gtr_model.hpp"
 #include "gtr_setup_kernel.hpp"
 #include "locus_lik_kernel.hpp"
+#include "locus_value_params.hpp"
 #include "pattern_kernels.hpp"
 #include <hipcub/hipcub.hpp>
 #include "pi_kernels.hpp"
@@ -104,6 +105,13 @@ struct tphip_plan {
     DevBuf<double> d_cat;     // [2 * ncat] category rates, then log weights
     DevBuf<int4> d_lik_ops;   // {code, taxon, node, tape slot} per op for the locus likelihood / gradient kernels
     double* d_tape = nullptr;   // reverse-mode tape of locus_grad_kernel, grown on demand
+    double* d_value_ws = nullptr;   // per-candidate eigen-systems + transition matrices of locus_value_kernel (one chunk)
+    size_t value_ws_bytes = 0;
+    int32_t value_cols = 0;         // columns per thread of locus_value_kernel (0: tree too large for it, eigenbasis kernel instead)
+    size_t value_lds = 0;
+    DevBuf<int4> d_value_ops;       // fused op stream of locus_value_kernel
+    DevBuf<int32_t> d_value_tip_node;
+    int32_t value_nops = 0;
     size_t tape_bytes = 0;
     // grow-only device arena + pinned host mirror for the host-pointer likelihood / gradient calls: the optimiser
     // makes thousands of small calls, so they must not hipMalloc or issue a dozen pageable copies each
@@ -159,9 +167,12 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_pi_chunk_locus.release(); plan->d_pi_chunk_index.release(); plan->d_times.release();
     plan->d_intervals.release(); plan->d_evals.release(); plan->d_tip_taxon.release(); plan->d_op_node.release();
     plan->d_lik_ops.release();
+    plan->d_value_ops.release();
+    plan->d_value_tip_node.release();
     plan->d_cat.release();
     free_host_buffers(plan);
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
+    if (plan->d_value_ws) { (void)hipFree(plan->d_value_ws); plan->d_value_ws = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
     if (plan->d_grad_params) { (void)hipFree(plan->d_grad_params); plan->d_grad_params = nullptr; }
@@ -298,6 +309,54 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         }
         e = p->d_lik_ops.upload(lops);
     }
+    if (e == hipSuccess) {
+        // locus_value_kernel's stream (layout: locus_value_params.hpp): TIP_SET + TIP_MUL -> CHERRY (whatever the branch
+        // lengths: the messages are table rows), PUSH carried by the TIP_SET / CHERRY that follows it, POP_MUL by the
+        // BRANCH it follows
+        const auto& ops = p->prog.ops;
+        const auto& node = p->prog.op_node;
+        std::vector<int4> vops;
+        std::vector<int32_t> tip_node(d->ntaxa, -1);
+        int32_t pending = 0, tip = 0;
+        bool ok = d->nnodes < 65536 && d->ntaxa * kValueTipRow * 8 < (1 << 30);
+        auto tip_bits = [&](int shift_pos, int fetch_pos) { return ((4 * (tip & 7)) << shift_pos) | (((tip & 7) == 0 ? 1 : 0) << fetch_pos); };
+        for (size_t i = 0; i < ops.size() && ok; ++i) {
+            const int32_t code = ops[i].code;
+            const bool has_next = i + 1 < ops.size();
+            if (code == OP_PUSH) {
+                if (!(has_next && ops[i + 1].code == OP_TIP_SET) || pending) ok = false;   // (a PUSH is always followed by a TIP_SET)
+                pending = OP_PUSH_BEFORE;
+            } else if (code == OP_TIP_SET && has_next && ops[i + 1].code == OP_TIP_MUL) {
+                int32_t x = OP_CHERRY | pending | tip_bits(12, 17);
+                const int32_t wa = tip >> 3;
+                ++tip;
+                x |= tip_bits(20, 25);
+                const int32_t wb = tip >> 3;
+                ++tip;
+                vops.push_back(make_int4(x, ops[i].taxon * kValueTipRow * 8, ops[i + 1].taxon * kValueTipRow * 8, wa | (wb << 16)));
+                tip_node[ops[i].taxon] = node[i];
+                tip_node[ops[i + 1].taxon] = node[i + 1];
+                pending = 0;
+                ++i;
+            } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
+                vops.push_back(make_int4(code | pending | tip_bits(12, 17), ops[i].taxon * kValueTipRow * 8, 0, tip >> 3));
+                tip_node[ops[i].taxon] = node[i];
+                ++tip;
+                pending = 0;
+            } else if (code == OP_BRANCH) {
+                const bool pop = has_next && ops[i + 1].code == OP_POP_MUL;
+                vops.push_back(make_int4(OP_BRANCH | (pop ? OP_POP_AFTER : 0), node[i] * 128, 0, 0));
+                if (pop) ++i;
+            } else {
+                ok = false;   // a POP_MUL that does not follow a BRANCH
+            }
+        }
+        vops.push_back(make_int4(kValueOpEnd, 0, 0, 0));
+        vops.push_back(make_int4(kValueOpEnd, 0, 0, 0));
+        if (ok) e = p->d_value_tip_node.upload(tip_node);
+        p->value_nops = ok ? (int32_t)vops.size() : 0;
+        if (ok && e == hipSuccess) e = p->d_value_ops.upload(vops);
+    }
     p->nnodes = d->nnodes;
     if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
     if (e == hipSuccess) e = p->d_fused_ops.upload(p->prog.fused_ops);
@@ -364,6 +423,22 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         p->lik_ok = p->lik_lds <= 150 * 1024;
         if (p->lik_ok && p->lik_lds > 64 * 1024)
             p->lik_ok = hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        // value kernel on transition matrices (locus_value_kernel.hpp): C columns per thread share the op decode and the
+        // scalar loads of a branch's matrix; parked siblings live in registers (template depth), LDS holds the tip matrices
+        // and the packed state masks
+        {
+            int cols = p->max_locus_cols >= 512 ? 2 : 1;
+            if (const char* env = getenv("TPHIP_VALUE_COLS")) cols = atoi(env) >= 2 ? 2 : 1;
+            p->value_cols = 0;
+            if (p->value_nops > 0 && p->prog.stack_depth <= kValueMaxDepth && !getenv("TPHIP_VALUE_EIGENBASIS")) {
+                const size_t need = (size_t)p->ntaxa * kValueTipRow * sizeof(double) + (size_t)p->nwords * cols * kLikBlock * sizeof(uint32_t);
+                if (need <= 96 * 1024 &&
+                    (need <= 64 * 1024 || locus_value_kernel_allow_lds(cols, p->prog.stack_depth, 96 * 1024) == hipSuccess)) {
+                    p->value_cols = cols;
+                    p->value_lds = need;
+                }
+            }
+        }
         // gradient kernel: staging helps it (95.6 -> 91.7 ms)
         p->grad_slots = kGradSlots;   // fewer accumulator addresses per branch when the tree would not fit otherwise
         while (p->grad_slots > 1 && (size_t)p->nnodes * (kGradEF + 2 * kGradWaves * p->grad_slots) * sizeof(double) > 100 * 1024)
@@ -778,6 +853,48 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
     L.stack_depth = p->prog.stack_depth; L.cand_locus = d_cand_locus; L.cand_exch = d_cand_exch;
     L.blen_vecs = d_blen_vecs; L.cand_vec = d_cand_vec; L.cand_scale = d_cand_scale; L.cand_pidx = d_cand_pidx;
     L.cand_pfac = d_cand_pfac; L.out = d_out;
+    if (p->value_cols > 0) {
+        // transition-matrix form: eigen-systems and matrices of a chunk of candidates, then the pruning kernel
+        const int C = p->value_cols;
+        const int nsplit = lik_nsplit(p, ncand, kLikBlock * C);
+        if (nsplit > 1) {
+            int rc = grow_part(p, (size_t)ncand * nsplit * sizeof(double));
+            if (rc) return rc;
+        }
+        const size_t per_cand = ((size_t)p->nnodes * 16 + 36) * sizeof(double);
+        int64_t chunk = std::max<int64_t>(1, (int64_t)(kValueWorkspaceBytes / per_cand));
+        chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, ((int64_t)1 << 30) / nsplit));   // grid.x limit
+        chunk = std::min<int64_t>(chunk, ncand);
+        const size_t need = (size_t)chunk * per_cand;
+        if (need > p->value_ws_bytes) {
+            if (p->d_value_ws) { HIP_TRY(hipFree(p->d_value_ws)); p->d_value_ws = nullptr; p->value_ws_bytes = 0; }
+            HIP_TRY(hipMalloc((void**)&p->d_value_ws, need));
+            p->value_ws_bytes = need;
+        }
+        double* d_eig = p->d_value_ws;
+        double* d_pmat = p->d_value_ws + (size_t)chunk * 36;
+        ValueParams V;
+        V.states = d_states; V.ncols_total = p->ncols; V.locus_offsets = p->d_offsets.p; V.col_weight = p->d_col_weight;
+        V.models = p->d_models.p; V.vops = p->d_value_ops.p; V.nvops = p->value_nops; V.ntaxa = p->ntaxa;
+        V.nnodes = p->nnodes; V.pmat = d_pmat; V.nsplit = nsplit;
+        V.tip_taxon = p->d_tip_taxon.p; V.nwords = p->nwords; V.tip_node = p->d_value_tip_node.p;
+        hipStream_t st = (hipStream_t)stream;
+        for (int64_t done = 0; done < ncand; done += chunk) {
+            const int64_t n = std::min<int64_t>(ncand - done, chunk);
+            HIP_TRY(launch_lik_eigen_kernel(st, p->d_models.p, d_cand_locus + done, d_cand_exch + done * 6, n, d_eig));
+            HIP_TRY(launch_lik_pmat_kernel(st, d_eig, d_blen_vecs, d_cand_vec + done, d_cand_scale + done, d_cand_pidx + done,
+                                           d_cand_pfac + done, n, p->nnodes, d_pmat));
+            V.cand_locus = d_cand_locus + done;
+            V.out = (nsplit > 1 ? p->d_part : d_out) + done * nsplit;
+            HIP_TRY(launch_locus_value_kernel(C, p->prog.stack_depth, dim3((unsigned)(n * nsplit)), p->value_lds, st, V));
+        }
+        HIP_TRY(hipGetLastError());
+        if (nsplit > 1) {
+            split_sum_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st>>>(p->d_part, d_out, ncand, nsplit, 1);
+            HIP_TRY(hipGetLastError());
+        }
+        return TPHIP_OK;
+    }
     if (!p->lik_ok) return fail(TPHIP_ERR_INVALID, "tree too large for the locus-likelihood kernel's LDS tables");
     const size_t lds = p->lik_lds;
     L.stage_states = p->lik_stage;
