@@ -143,8 +143,10 @@ def _shared_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
 
 
-STAGE1_BLOCK_LOCI = 2048   # loci fitted together (bounds host memory: 2048 x 202 models x 9-point stencils = 3.7 M candidates at most;
-                           # large enough for the device-resident optimisers of stage1_device.py and to amortise straggler loci)
+STAGE1_BLOCK_LOCI = 8192   # loci fitted together (bounds memory: 8192 x 202 models x 9-point stencils = 15 M candidates at most).
+                           # An optimiser iteration costs a fixed ~7 ms of small launches whatever the block holds, and a block runs
+                           # until its slowest locus has converged: 8192 loci x 1000 x 64 taxa take 6.4-7.1 s in blocks of 2048,
+                           # 5.4 s in blocks of 4096, 4.5-4.9 s in one block
 
 
 def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, blen, leaf, T, times, intervals,
