@@ -793,6 +793,102 @@ def test_locus_loglik_vs_oracle(oracle):
         plan.close()
 
 
+def _balanced_tree(levels, rng):
+    """Post-order arrays of a perfectly balanced binary tree with 2**levels leaves: levels - 1 partials are parked at the
+    deepest point.  The value kernel's register stack holds 5, so 6 levels = 64 leaves need all of them and 7 levels fall
+    back to the eigenbasis kernel with its LDS stack."""
+    parent, blen, leaf = [], [], []
+    counter = [0]
+
+    def build(level):
+        if level == 0:
+            parent.append(-1); blen.append(float(rng.uniform(0.01, 0.3))); leaf.append(counter[0]); counter[0] += 1
+            return len(parent) - 1
+        a = build(level - 1)
+        b = build(level - 1)
+        parent.append(-1); blen.append(float(rng.uniform(0.01, 0.3))); leaf.append(-1)
+        me = len(parent) - 1
+        parent[a] = me; parent[b] = me
+        return me
+
+    build(levels)
+    blen[-1] = 0.0
+    return np.array(parent, np.int32), np.array(blen), np.array(leaf, np.int32)
+
+
+def test_locus_value_kernel_codes_trees_and_widths(oracle, monkeypatch):
+    """The transition-matrix value kernel (locus_value_kernel.hpp) against the oracle and against the eigenbasis kernel it
+    replaces: every IUPAC state set, gaps and zero bytes; one and two columns per thread; a caterpillar (stack depth 1), a
+    balanced 64-leaf tree (all 5 register slots) and a balanced 128-leaf tree (deeper than the register stack: falls
+    back); column weights; a near-zero and a long branch."""
+    engine = _engine()
+    rng = np.random.default_rng(11)
+    ncols, nloci = 700, 3
+    for levels in (3, 6, 7):
+        parent, blen, leaf = _balanced_tree(levels, rng)
+        ntaxa = 1 << levels
+        blen[1] = 1e-9
+        blen[3] = 4.0
+        st = (1 << rng.integers(0, 4, (ntaxa, ncols * nloci))).astype(np.uint8)
+        st[:, ::3] = st[0, ::3]                                    # a third of the columns constant
+        amb = rng.random(st.shape) < 0.08
+        st[amb] = rng.integers(0, 16, int(amb.sum())).astype(np.uint8)   # every mask 0..15 (0 is read as a gap)
+        off = np.array([0, ncols - 13, 2 * ncols, 3 * ncols])
+        pi = rng.dirichlet([5, 5, 5, 5], nloci)
+        w = rng.integers(1, 5, ncols * nloci).astype(np.float64)
+        ncand = 17
+        cl = rng.integers(0, nloci, ncand)
+        ce = np.exp(rng.normal(0, 0.5, (ncand, 6)))
+        cb = blen[None, :] * np.exp(rng.normal(0, 0.3, (ncand, len(parent))))
+        results = {}
+        for variant in ("1", "2", "eigenbasis"):
+            monkeypatch.delenv("TPHIP_VALUE_COLS", raising=False)
+            monkeypatch.delenv("TPHIP_VALUE_EIGENBASIS", raising=False)
+            if variant == "eigenbasis":
+                monkeypatch.setenv("TPHIP_VALUE_EIGENBASIS", "1")
+            else:
+                monkeypatch.setenv("TPHIP_VALUE_COLS", variant)
+            plan = engine.Plan(ntaxa, parent, blen, leaf, off, pi, np.ones((nloci, 6)), 3, [1], [[0, 1]])
+            plain = plan.locus_loglik(st, cb, cl, ce)
+            plan.set_column_weights(w)
+            results[variant] = (plain, plan.locus_loglik(st, cb, cl, ce))
+            plan.close()
+        for variant in ("1", "2"):
+            for k in (0, 1):
+                assert np.max(np.abs(results[variant][k] - results["eigenbasis"][k]) / np.abs(results["eigenbasis"][k])) < 1e-11, (levels, variant)
+        for c in range(ncand):
+            l = int(cl[c])
+            ref = oracle.locus_loglik(st[:, off[l]:off[l + 1]], parent, cb[c], leaf, pi[l], ce[c])
+            assert abs(results["2"][0][c] - ref) < 1e-9 * abs(ref), (levels, c)
+    # a caterpillar: one parked partial at most
+    nt = 12
+    parent, blen, leaf = [], [], []
+    parent.append(-1); blen.append(0.1); leaf.append(0)
+    prev = 0
+    for t in range(1, nt):
+        parent.append(-1); blen.append(0.05 + 0.01 * t); leaf.append(t)
+        tip = len(parent) - 1
+        parent.append(-1); blen.append(0.02 * t); leaf.append(-1)
+        me = len(parent) - 1
+        parent[prev] = me; parent[tip] = me
+        prev = me
+    blen[-1] = 0.0
+    parent, blen, leaf = np.array(parent, np.int32), np.array(blen), np.array(leaf, np.int32)
+    st = (1 << rng.integers(0, 4, (nt, 300))).astype(np.uint8)
+    st[:, 100:] = st[0, 100:]
+    st[3, 100:200] = 15
+    off = np.array([0, 300])
+    pi = np.array([[0.3, 0.2, 0.2, 0.3]])
+    monkeypatch.delenv("TPHIP_VALUE_COLS", raising=False)
+    monkeypatch.delenv("TPHIP_VALUE_EIGENBASIS", raising=False)
+    plan = engine.Plan(nt, parent, blen, leaf, off, pi, np.ones((1, 6)), 3, [1], [[0, 1]])
+    ce = np.array([[1.0, 2.0, 0.5, 0.7, 3.0, 1.0]])
+    got = plan.locus_loglik(st, blen[None, :], [0], ce)
+    plan.close()
+    ref = oracle.locus_loglik(st, parent, blen, leaf, pi[0], ce[0])
+    assert abs(got[0] - ref) < 1e-10 * abs(ref)
+
+
 def _fd_gradient(oracle, st, parent, leaf, pi, exch, blen, h=1e-5):
     """Central differences of the oracle's log-likelihood w.r.t. the six exchangeabilities and every log branch
     length (the independent check of the reverse-mode kernel)."""
