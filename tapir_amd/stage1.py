@@ -85,6 +85,16 @@ def total_factor(pi, exch):
     return (w * exch).sum(axis=-1)
 
 
+def _backtrack(t, ft, f0, gd):
+    """Next trial step after `t` failed the Armijo test: the minimiser of the parabola through f(0) = f0, f'(0) = gd < 0 and
+    f(t) = ft, kept within [0.1 t, 0.5 t] (0.25 t where the trial value is not finite).  Plain halving needed 6-8 rounds --
+    6-8 likelihood calls one after the other -- whenever one locus of a batch wanted a step of 1/100."""
+    den = 2.0 * (ft - f0 - gd * t)
+    good = np.isfinite(ft) & (den > 0)
+    tq = np.where(good, -gd * t * t / np.where(good, den, 1.0), 0.25 * t)
+    return np.clip(tq, 0.1 * t, 0.5 * t)
+
+
 class _LBFGS:
     """Batched L-BFGS (maximisation written as minimisation of -lnL) over P independent problems of dimension D.
     `value(X, idx)` evaluates points X[len(idx), D] of problems idx; `value_and_grad(X, idx)` adds gradients."""
@@ -203,8 +213,8 @@ class _LBFGS:
                 ok &= np.isfinite(ft)
                 acc = pending[ok]
                 xnew[acc] = xt[ok]; fnew[acc] = ft[ok]
+                t[pending[~ok]] = _backtrack(t[pending[~ok]], ft[~ok], fl[pending[~ok]], gd[pending[~ok]])
                 pending = pending[~ok]
-                t[pending] *= 0.5
             failed = np.zeros(live.size, bool)
             failed[pending] = True  # no decrease found: treat as converged at the current point
             fx, gx, hx = self._vg(xnew, live)
@@ -220,6 +230,9 @@ class _LBFGS:
             rho[slot] = 0.0
             S[slot, sl] = s_; Y[slot, sl] = y_
             rho[slot, sl] = np.where(upd, 1.0 / np.where(upd, sy, 1.0), 0.0)
+            # (measured: scaling the curvature diagonal D by the secant factor s.y / (y.D y), the textbook choice, makes the steps
+            #  far too short here -- 250 iterations instead of 40 on 16 loci x 20 000 x 64 taxa; the bare 1 / curvature overshoots
+            #  the unit step for about half the loci of an iteration, which costs one more likelihood call, not an iteration)
             gamma_all[sl] = np.where(upd, sy / np.maximum(yy, 1e-300), gamma)
             nhist[sl] += upd
             df = fl - fx

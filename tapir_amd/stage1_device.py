@@ -27,6 +27,14 @@ def available(plan):
         return False
 
 
+def _backtrack(torch, t, ft, f0, gd):
+    """stage1._backtrack on tensors: next trial step from the parabola through f(0), f'(0) and the failed trial."""
+    den = 2.0 * (ft - f0 - gd * t)
+    good = torch.isfinite(ft) & (den > 0)
+    tq = torch.where(good, -gd * t * t / torch.where(good, den, torch.ones_like(den)), 0.25 * t)
+    return torch.maximum(torch.minimum(tq, 0.5 * t), 0.1 * t)
+
+
 class DeviceSubmodelFitter:
     def __init__(self, plan, d_states_ptr, stash, w6, locus, cls, active, stencil, need, kk, h, device=0):
         import torch
@@ -162,8 +170,9 @@ class DeviceSubmodelFitter:
                 ok = (ft <= fl[pending] + 1e-4 * t[pending] * gd[pending]) & torch.isfinite(ft)
                 acc = pending[ok]
                 xnew[acc], fnew[acc] = xt[ok], ft[ok]
-                pending = pending[~ok]
-                t[pending] = t[pending] * 0.5
+                bad = ~ok
+                t[pending[bad]] = _backtrack(torch, t[pending[bad]], ft[bad], fl[pending[bad]], gd[pending[bad]])
+                pending = pending[bad]
             failed = torch.zeros(n, dtype=torch.bool, device=dev)
             failed[pending] = True
             fx, gx = self.value_and_grad(xnew, live)
@@ -304,8 +313,9 @@ class DeviceLBFGS:
                 ok = (ft <= fl[pending] + 1e-4 * t[pending] * gd[pending]) & torch.isfinite(ft)
                 acc = pending[ok]
                 xnew[acc], fnew[acc] = xt[ok], ft[ok]
-                pending = pending[~ok]
-                t[pending] = t[pending] * 0.5
+                bad = ~ok
+                t[pending[bad]] = _backtrack(torch, t[pending[bad]], ft[bad], fl[pending[bad]], gd[pending[bad]])
+                pending = pending[bad]
             failed = torch.zeros(n, dtype=torch.bool, device=dev)
             failed[pending] = True
             fx, gx, hx = self.vg(xnew, live)
