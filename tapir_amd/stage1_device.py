@@ -226,127 +226,167 @@ class DeviceLBFGS:
         self.lo, self.hi = lo, hi
 
     def run(self):
+        """Fixed-shape formulation: the optimiser's state covers a WORKING SET of problems (all of them at first) and every
+        update is a masked whole-array operation -- no gather / scatter per correction pair, which made an iteration ~800
+        small launches (7-11 ms) whatever the block held.  Only the likelihood calls take index lists (converged problems
+        cost no kernel work), and the working set is compacted whenever fewer than 70 % of its rows are still live."""
         torch = self.torch
-        x = self.x
-        P, D = x.shape
-        dev = x.device
+        P, D = self.x.shape
+        dev = self.x.device
         f64 = torch.float64
-        live = torch.arange(P, device=dev)
-        f, g, hd = self.vg(x, live)
+        inf = float("inf")
+        ids = torch.arange(P, device=dev)                  # original index of every working-set row
+        x = self.x.clone()
+        f, g, hd = self.vg(x, ids)
         hdiag = hd.clone() if hd is not None else torch.full((P, D), float("nan"), dtype=f64, device=dev)
         m = self.m
         S = torch.zeros((m, P, D), dtype=f64, device=dev)
         Y = torch.zeros((m, P, D), dtype=f64, device=dev)
         rho = torch.zeros((m, P), dtype=f64, device=dev)
-        gamma_all = torch.ones(P, dtype=f64, device=dev)
+        gamma = torch.ones(P, dtype=f64, device=dev)
         nhist = torch.zeros(P, dtype=torch.int64, device=dev)
-        converged = torch.zeros(P, dtype=torch.bool, device=dev)
-        last_df = torch.full((P,), float("inf"), dtype=f64, device=dev)
+        conv = torch.zeros(P, dtype=torch.bool, device=dev)
+        last_df = torch.full((P,), inf, dtype=f64, device=dev)
         fresh = torch.zeros(P, dtype=torch.bool, device=dev)
         iters = torch.zeros(P, dtype=torch.int64, device=dev)
+        out_x, out_f = self.x.clone(), torch.zeros(P, dtype=f64, device=dev)
+        out_iters = torch.zeros(P, dtype=torch.int64, device=dev)
         MAXS = _s1.MAX_LOG_STEP
+
+        def nz(mask):
+            return torch.nonzero(mask, as_tuple=True)[0]
+
         for it in range(self.maxit):
-            live = torch.nonzero(~converged, as_tuple=True)[0]
-            if live.numel() == 0:
+            W = x.shape[0]
+            nlive = W - int(conv.sum())
+            if nlive == 0:
                 break
-            xl, fl, gl = x[live], f[live], g[live]
+            if nlive < 0.7 * W:
+                # compact the working set: results of the rows that leave go to the output arrays
+                gone, keep = nz(conv), nz(~conv)
+                out_x[ids[gone]], out_f[ids[gone]], out_iters[ids[gone]] = x[gone], f[gone], iters[gone]
+                ids, x, f, g, hdiag = ids[keep], x[keep], f[keep], g[keep], hdiag[keep]
+                S, Y, rho = S[:, keep].contiguous(), Y[:, keep].contiguous(), rho[:, keep].contiguous()
+                gamma, nhist, last_df, fresh, iters = gamma[keep], nhist[keep], last_df[keep], fresh[keep], iters[keep]
+                conv = torch.zeros(keep.numel(), dtype=torch.bool, device=dev)
+                W = keep.numel()
+            live = ~conv
+            # two-loop recursion, newest pair first, on the whole working set (rho = 0 marks "no pair")
             slots = [(it - 1 - j) % m for j in range(min(it, m))]
-            q = gl.clone()
+            q = g.clone()
             alpha = {}
             for i in slots:
-                a = rho[i, live] * (S[i, live] * q).sum(dim=1)
+                a = rho[i] * (S[i] * q).sum(dim=1)
                 alpha[i] = a
-                q = q - a.unsqueeze(1) * Y[i, live]
-            gamma = gamma_all[live]
-            hl = hdiag[live]
-            okh = torch.isfinite(hl) & (hl > 1e-12)
-            have_h = torch.isfinite(hl).any(dim=1)
-            r = torch.where(okh, 1.0 / torch.where(okh, hl, torch.ones_like(hl)), gamma.unsqueeze(1).expand_as(hl)) * q
+                q = torch.addcmul(q, Y[i], a.unsqueeze(1), value=-1.0)
+            okh = torch.isfinite(hdiag) & (hdiag > 1e-12)
+            have_h = torch.isfinite(hdiag).any(dim=1)
+            r = torch.where(okh, 1.0 / torch.where(okh, hdiag, torch.ones_like(hdiag)), gamma.unsqueeze(1).expand_as(hdiag)) * q
             for i in reversed(slots):
-                bcoef = rho[i, live] * (Y[i, live] * r).sum(dim=1)
-                r = r + (alpha[i] - bcoef).unsqueeze(1) * S[i, live]
+                bcoef = rho[i] * (Y[i] * r).sum(dim=1)
+                r = torch.addcmul(r, S[i], (alpha[i] - bcoef).unsqueeze(1))
             d = (-r).clamp(-MAXS, MAXS)
-            gd = (gl * d).sum(dim=1)
+            gd = (g * d).sum(dim=1)
             bad = ~(gd < 0)
-            d = torch.where(bad.unsqueeze(1), -gl, d)
-            gd = torch.where(bad, -(gl * gl).sum(dim=1), gd)
-            scale_f = 1.0 + fl.abs()
-            gmax = gl.abs().max(dim=1).values
-            stop = (last_df[live] <= self.ftol * scale_f) & (-gd <= self.ptol * scale_f) & (gmax <= self.gtol * scale_f)
-            stop |= gmax <= 1e-9
-            any_stop = bool(stop.any())
-            if any_stop and self.escape is not None:
-                si = live[stop]
-                xs, moved = self.escape(si, xl[stop], gl[stop])
-                if bool(moved.any()):
-                    mi = si[moved]
-                    x[mi] = xs[moved]
-                    fm, gm, hm = self.vg(x[mi], mi)
-                    f[mi], g[mi] = fm, gm
-                    if hm is not None:
-                        hdiag[mi] = hm
-                    rho[:, mi] = 0.0
-                    nhist[mi] = 0
-                    last_df[mi] = float("inf")
+            d = torch.where(bad.unsqueeze(1), -g, d)
+            gd = torch.where(bad, -(g * g).sum(dim=1), gd)
+            scale_f = 1.0 + f.abs()
+            gmax = g.abs().max(dim=1).values
+            stop = (last_df <= self.ftol * scale_f) & (-gd <= self.ptol * scale_f) & (gmax <= self.gtol * scale_f)
+            stop = (stop | (gmax <= 1e-9)) & live
+            if bool(stop.any()):
+                if self.escape is not None:
+                    si = nz(stop)
+                    xs, moved = self.escape(ids[si], x[si], g[si])
+                    if bool(moved.any()):
+                        mi = si[moved]
+                        x[mi] = xs[moved]
+                        fm, gm, hm = self.vg(x[mi], ids[mi])
+                        f[mi], g[mi] = fm, gm
+                        if hm is not None:
+                            hdiag[mi] = hm
+                        rho[:, mi] = 0.0
+                        nhist[mi] = 0
+                        last_df[mi] = inf
+                        continue          # every direction is recomputed from the new points
+                conv = conv | stop
+                live = ~conv
+                if not bool(live.any()):
                     continue
-            if any_stop:
-                converged[live[stop]] = True
-                keep = ~stop
-                if not bool(keep.any()):
-                    continue
-                live = live[keep]
-                xl, fl, gl, d, gd, hl, have_h, gamma = xl[keep], fl[keep], gl[keep], d[keep], gd[keep], hl[keep], have_h[keep], gamma[keep]
-            n = live.numel()
-            step0 = torch.where((nhist[live] == 0) & ~have_h,
-                                torch.minimum(torch.ones(n, dtype=f64, device=dev), 1.0 / gl.abs().max(dim=1).values.clamp(min=1e-300)),
-                                torch.ones(n, dtype=f64, device=dev))
+            # line search (Armijo, parabolic backtracking) on the live problems
+            step0 = torch.where((nhist == 0) & ~have_h, (1.0 / gmax.clamp(min=1e-300)).clamp(max=1.0), torch.ones_like(gmax))
             dmax = d.abs().max(dim=1).values
             t = torch.minimum(step0, MAXS / dmax.clamp(min=1e-300))
-            xnew, fnew = xl.clone(), fl.clone()
-            pending = torch.arange(n, device=dev)
-            for _ in range(30):
-                if pending.numel() == 0:
+            xnew, fnew = x.clone(), f.clone()
+            pend = live.clone()
+            all_rows = bool(live.all())
+            for rnd in range(30):
+                pidx = None if (rnd == 0 and all_rows) else nz(pend)
+                if pidx is not None and pidx.numel() == 0:
                     break
-                xt = xl[pending] + t[pending].unsqueeze(1) * d[pending]
-                xt = torch.maximum(torch.minimum(xt, self.hi), self.lo)
-                ft = self.value(xt, live[pending])
-                ok = (ft <= fl[pending] + 1e-4 * t[pending] * gd[pending]) & torch.isfinite(ft)
-                acc = pending[ok]
-                xnew[acc], fnew[acc] = xt[ok], ft[ok]
-                bad = ~ok
-                t[pending[bad]] = _backtrack(torch, t[pending[bad]], ft[bad], fl[pending[bad]], gd[pending[bad]])
-                pending = pending[bad]
-            failed = torch.zeros(n, dtype=torch.bool, device=dev)
-            failed[pending] = True
-            fx, gx, hx = self.vg(xnew, live)
+                if pidx is None:
+                    xt = torch.maximum(torch.minimum(torch.addcmul(x, d, t.unsqueeze(1)), self.hi), self.lo)
+                    ft = self.value(xt, ids)
+                    ok = (ft <= f + 1e-4 * t * gd) & torch.isfinite(ft)
+                    xnew = torch.where(ok.unsqueeze(1), xt, xnew)
+                    fnew = torch.where(ok, ft, fnew)
+                    t = torch.where(ok, t, _backtrack(torch, t, ft, f, gd))
+                    pend = ~ok
+                    if bool(ok.all()):
+                        break
+                else:
+                    tp, fp, gp = t[pidx], f[pidx], gd[pidx]
+                    xt = torch.maximum(torch.minimum(torch.addcmul(x[pidx], d[pidx], tp.unsqueeze(1)), self.hi), self.lo)
+                    ft = self.value(xt, ids[pidx])
+                    ok = (ft <= fp + 1e-4 * tp * gp) & torch.isfinite(ft)
+                    acc = pidx[ok]
+                    xnew[acc], fnew[acc] = xt[ok], ft[ok]
+                    rej = ~ok
+                    t[pidx[rej]] = _backtrack(torch, tp[rej], ft[rej], fp[rej], gp[rej])
+                    pend[acc] = False
+            failed = pend & live
+            if all_rows:
+                fx, gx, hx = self.vg(xnew, ids)
+            else:
+                li = nz(live)
+                fl_, gl_, hl_ = self.vg(xnew[li], ids[li])
+                fx, gx = f.clone(), g.clone()
+                fx[li], gx[li] = fl_, gl_
+                hx = None
+                if hl_ is not None:
+                    hx = hdiag.clone()
+                    hx[li] = hl_
             if hx is not None:
-                hdiag[live] = hx
-            s_ = xnew - xl
-            y_ = gx - gl
+                hdiag = hx
+            lv = live.unsqueeze(1)
+            s_ = torch.where(lv, xnew - x, torch.zeros_like(x))
+            y_ = torch.where(lv, gx - g, torch.zeros_like(g))
             sy = (s_ * y_).sum(dim=1)
             yy = (y_ * y_).sum(dim=1)
-            upd = (sy > 1e-12 * torch.sqrt((s_ * s_).sum(dim=1) * yy + 1e-300)) & ~failed
+            upd = (sy > 1e-12 * torch.sqrt((s_ * s_).sum(dim=1) * yy + 1e-300)) & ~failed & live
             slot = it % m
-            rho[slot] = 0.0
-            S[slot, live] = s_
-            Y[slot, live] = y_
-            rho[slot, live] = torch.where(upd, 1.0 / torch.where(upd, sy, torch.ones_like(sy)), torch.zeros_like(sy))
-            gamma_all[live] = torch.where(upd, sy / yy.clamp(min=1e-300), gamma)
-            nhist[live] += upd.to(torch.int64)
-            df = fl - fx
-            last_df[live] = torch.where(failed, torch.zeros_like(df), df)
-            retry = failed & (nhist[live] > 0)
-            ri = live[retry]
-            rho[:, ri] = 0.0
-            nhist[ri] = 0
-            last_df[ri] = float("inf")
-            done = (failed & ~retry & fresh[live]) | (failed & ~retry & (nhist[live] == 0))
-            fresh[live] = retry
-            x[live], f[live], g[live] = xnew, fx, gx
-            iters[live] += 1
-            converged[live[done]] = True
-        self.iters = iters
-        return x, f
+            S[slot], Y[slot] = s_, y_
+            rho[slot] = torch.where(upd, 1.0 / torch.where(upd, sy, torch.ones_like(sy)), torch.zeros_like(sy))
+            gamma = torch.where(upd, sy / yy.clamp(min=1e-300), gamma)
+            nhist = nhist + upd.to(torch.int64)
+            df = f - fx
+            last_df = torch.where(live, torch.where(failed, torch.zeros_like(df), df), last_df)
+            # a failed line search with correction pairs in play: forget them and try once more along the (preconditioned)
+            # gradient before giving the point up as converged
+            retry = failed & (nhist > 0)
+            rho = torch.where(retry.unsqueeze(0), torch.zeros_like(rho), rho)
+            nhist = torch.where(retry, torch.zeros_like(nhist), nhist)
+            last_df = torch.where(retry, torch.full_like(last_df, inf), last_df)
+            done = failed & ~retry & (fresh | (nhist == 0))
+            fresh = torch.where(live, retry, fresh)
+            x = torch.where(lv, xnew, x)
+            f = torch.where(live, fx, f)
+            g = torch.where(lv, gx, g)
+            iters = iters + live.to(torch.int64)
+            conv = conv | done
+        out_x[ids], out_f[ids], out_iters[ids] = x, f, iters
+        self.iters = out_iters
+        return out_x, out_f
 
 
 class DeviceGrmFitter:
