@@ -244,6 +244,8 @@ struct GradParams {
     int32_t nslots;             // 4, 2 or 1: accumulator addresses per (wave, branch) that fit the LDS budget of this tree
     double* out_d2logt;         // [items][nnodes] d2 lnL / d (log t_b)^2 with everything else fixed (the diagonal of the
                                 // Hessian: preconditions the optimiser), or null
+    const double* cand_eig;     // [ncand][36] eigen-systems computed beforehand by lik_eigen_kernel (one thread per candidate),
+                                // or null: thread 0 of the workgroup diagonalises Q itself (~20 us per work item)
 };
 
 __device__ inline double lik_wave_sum(double v) {
@@ -295,7 +297,11 @@ __global__ __launch_bounds__(kGradBlock, TPHIP_GRAD_MIN_WAVES) void locus_grad_k
             continue;
         }
         const double* pig = P.models[locus].pi;
-        if (tid == 0) lik_eigen(pig, P.cand_exch + (size_t)cand * 6, eig);
+        if (G.cand_eig) {
+            if (tid < 36) eig[tid] = G.cand_eig[(size_t)cand * 36 + tid];
+        } else if (tid == 0) {
+            lik_eigen(pig, P.cand_exch + (size_t)cand * 6, eig);
+        }
         __syncthreads();
         const double* bl = P.blen_vecs + (size_t)P.cand_vec[cand] * nn;
         const double bscale = P.cand_scale[cand], pfac = P.cand_pfac[cand];

@@ -105,6 +105,8 @@ struct tphip_plan {
     DevBuf<double> d_cat;     // [2 * ncat] category rates, then log weights
     DevBuf<int4> d_lik_ops;   // {code, taxon, node, tape slot} per op for the locus likelihood / gradient kernels
     double* d_tape = nullptr;   // reverse-mode tape of locus_grad_kernel, grown on demand
+    double* d_grad_eig = nullptr;   // per-candidate eigen-systems for locus_grad_kernel
+    size_t grad_eig_bytes = 0;
     double* d_value_ws = nullptr;   // per-candidate eigen-systems + transition matrices of locus_value_kernel (one chunk)
     size_t value_ws_bytes = 0;
     int32_t value_cols = 0;         // columns per thread of locus_value_kernel (0: tree too large for it, eigenbasis kernel instead)
@@ -173,6 +175,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     free_host_buffers(plan);
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_value_ws) { (void)hipFree(plan->d_value_ws); plan->d_value_ws = nullptr; }
+    if (plan->d_grad_eig) { (void)hipFree(plan->d_grad_eig); plan->d_grad_eig = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
     if (plan->d_grad_params) { (void)hipFree(plan->d_grad_params); plan->d_grad_params = nullptr; }
@@ -965,6 +968,18 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
         p->tape_bytes = need;
     }
     G.tape = p->d_tape;
+    // eigen-systems of the candidates by one thread each (locus_value_launch.hip) instead of thread 0 of every work item
+    G.cand_eig = nullptr;
+    {
+        const size_t need_eig = (size_t)ncand * 36 * sizeof(double);
+        if (need_eig > p->grad_eig_bytes) {
+            if (p->d_grad_eig) { HIP_TRY(hipFree(p->d_grad_eig)); p->d_grad_eig = nullptr; p->grad_eig_bytes = 0; }
+            HIP_TRY(hipMalloc((void**)&p->d_grad_eig, need_eig));
+            p->grad_eig_bytes = need_eig;
+        }
+        HIP_TRY(launch_lik_eigen_kernel((hipStream_t)stream, p->d_models.p, d_cand_locus, d_cand_exch, ncand, p->d_grad_eig));
+        G.cand_eig = p->d_grad_eig;
+    }
     if (!p->d_grad_params) HIP_TRY(hipMalloc((void**)&p->d_grad_params, sizeof(GradParams)));
     HIP_TRY(hipMemcpyAsync(p->d_grad_params, &G, sizeof(GradParams), hipMemcpyHostToDevice, (hipStream_t)stream));
     locus_grad_kernel<<<dim3((unsigned)grid), dim3(kGradBlock), lds, (hipStream_t)stream>>>((const GradParams*)p->d_grad_params);
