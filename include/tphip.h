@@ -236,7 +236,10 @@ int tphip_last_eval_count(tphip_plan *plan, int64_t *evals);
  * ---------------------------------------------------------------------------------------------- */
 /* Pinned host memory for the buffers of the host-pointer calls: with it the copies are direct DMA and the per-column
  * results travel while the PI kernels run; ordinary (pageable) memory works too, through the runtime's staged copies.
- * NULL (and tphip_last_error) when it fails.  Free with tphip_host_free. */
+ * When EVERY buffer of a tphip_site_rates / tphip_run_fused call is pinned (the input `states` too) and the batch has
+ * at least 2^21 columns, the library runs it as a pipeline of two locus groups (the second upload under the first
+ * group's kernels); outputs are identical to the unsplit run.  NULL (and tphip_last_error) when the allocation fails.
+ * Free with tphip_host_free. */
 void *tphip_host_alloc(size_t bytes);
 int tphip_host_free(void *ptr);
 int tphip_site_rates(tphip_plan *plan, const uint8_t *states, double *rate, double *subst, double *lnl,

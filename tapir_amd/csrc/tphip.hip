@@ -80,8 +80,18 @@ struct Scratch {
 struct tphip_host_buffers;
 static void free_host_buffers(struct tphip_plan* p);
 
+struct tphip_saved_desc;
+static void free_parts(struct tphip_plan* p);
+
 struct tphip_plan {
     tphip_host_buffers* hostbuf = nullptr;   // device buffers, streams and events of the host-pointer entry points
+    // host-pointer entry points on big batches: the loci are cut into `host_split` groups, each a plan of its own with its
+    // own streams, so that the upload of group k + 1 runs under the kernels of group k (host_run)
+    tphip_saved_desc* saved = nullptr;       // deep copy of the descriptor the plan was created from
+    std::vector<tphip_plan*> parts;
+    std::vector<int64_t> part_locus;         // [parts + 1] locus boundaries
+    int32_t host_split = 1;
+    bool is_part = false;
     int32_t device = 0;
     int32_t ntaxa = 0;
     int64_t nloci = 0, ncols = 0;
@@ -173,6 +183,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     plan->d_value_tip_node.release();
     plan->d_cat.release();
     free_host_buffers(plan);
+    free_parts(plan);
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_value_ws) { (void)hipFree(plan->d_value_ws); plan->d_value_ws = nullptr; }
     if (plan->d_grad_eig) { (void)hipFree(plan->d_grad_eig); plan->d_grad_eig = nullptr; }
@@ -183,6 +194,74 @@ int tphip_plan_destroy(tphip_plan* plan) {
     if (plan->h_arena) { (void)hipHostFree(plan->h_arena); plan->h_arena = nullptr; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
     delete plan;
+    return TPHIP_OK;
+}
+
+struct tphip_saved_desc {
+    tphip_plan_desc d;
+    std::vector<int32_t> parent, leaf, times, intervals;
+    std::vector<double> blen, pi, exch, cat_rate, cat_weight;
+    std::vector<int64_t> offsets;
+};
+
+static tphip_saved_desc* save_desc(const tphip_plan_desc* d) {
+    tphip_saved_desc* s = new tphip_saved_desc();
+    s->d = *d;
+    s->parent.assign(d->parent, d->parent + d->nnodes);
+    s->blen.assign(d->branch_len, d->branch_len + d->nnodes);
+    s->leaf.assign(d->leaf_taxon, d->leaf_taxon + d->nnodes);
+    s->offsets.assign(d->locus_offsets, d->locus_offsets + d->nloci + 1);
+    s->pi.assign(d->pi, d->pi + 4 * d->nloci);
+    s->exch.assign(d->exch, d->exch + 6 * d->nloci);
+    if (d->n_t) s->times.assign(d->times, d->times + d->n_t);
+    if (d->n_i) s->intervals.assign(d->intervals, d->intervals + 2 * (size_t)d->n_i);
+    if (d->ncat > 0 && d->cat_rate && d->cat_weight) {
+        s->cat_rate.assign(d->cat_rate, d->cat_rate + d->ncat);
+        s->cat_weight.assign(d->cat_weight, d->cat_weight + d->ncat);
+    }
+    return s;
+}
+
+static void free_parts(tphip_plan* p) {
+    for (tphip_plan* q : p->parts) (void)tphip_plan_destroy(q);
+    p->parts.clear();
+    delete p->saved;
+    p->saved = nullptr;
+}
+
+// The plans of the locus groups of a host-pointer run (created on first use): boundaries at the loci nearest to equal
+// column counts; each group is an ordinary plan over its own loci (same tree, schedule and options).
+static int make_parts(tphip_plan* p) {
+    if (!p->parts.empty()) return TPHIP_OK;
+    const tphip_saved_desc& S = *p->saved;
+    const int64_t L = p->nloci, n = p->ncols;
+    const int K = (int)std::min<int64_t>(p->host_split, L);
+    std::vector<int64_t> cut(1, 0);
+    for (int k = 1; k < K; ++k) {
+        const int64_t target = n * k / K;
+        int64_t l = std::lower_bound(S.offsets.begin(), S.offsets.end(), target) - S.offsets.begin();
+        l = std::max<int64_t>(cut.back() + 1, std::min<int64_t>(l, L - (K - k)));
+        cut.push_back(l);
+    }
+    cut.push_back(L);
+    for (size_t k = 0; k + 1 < cut.size(); ++k) {
+        const int64_t l0 = cut[k], l1 = cut[k + 1];
+        std::vector<int64_t> off(S.offsets.begin() + l0, S.offsets.begin() + l1 + 1);
+        for (int64_t& o : off) o -= S.offsets[l0];
+        tphip_plan_desc d = S.d;
+        d.parent = S.parent.data(); d.branch_len = S.blen.data(); d.leaf_taxon = S.leaf.data();
+        d.nloci = l1 - l0; d.locus_offsets = off.data(); d.pi = S.pi.data() + 4 * l0; d.exch = S.exch.data() + 6 * l0;
+        d.times = S.times.empty() ? nullptr : S.times.data();
+        d.intervals = S.intervals.empty() ? nullptr : S.intervals.data();
+        d.cat_rate = S.cat_rate.empty() ? nullptr : S.cat_rate.data();
+        d.cat_weight = S.cat_weight.empty() ? nullptr : S.cat_weight.data();
+        tphip_plan* q = nullptr;
+        const int rc = tphip_plan_create(&d, &q);
+        if (rc) { for (tphip_plan* r : p->parts) (void)tphip_plan_destroy(r); p->parts.clear(); return rc; }
+        q->is_part = true;
+        p->parts.push_back(q);
+    }
+    p->part_locus = cut;
     return TPHIP_OK;
 }
 
@@ -518,6 +597,9 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         p->ws_spill = off; off = align_up(off + rows * 12 * kSiteBlock * sizeof(double), 256);
     }
     p->ws_total = off + 256;
+    p->saved = save_desc(d);
+    p->host_split = 2;   // measured (C3 / C4, pinned buffers): 1 group 16.5 / 151 ms, 2: 12.8 / 127, 3: 17.3 / 154, 4: 14.9 / 140, 6: 15.2 / 135
+    if (const char* hs = getenv("TPHIP_HOST_SPLIT")) p->host_split = std::max(1, std::min(64, atoi(hs)));
     *out = p;
     return TPHIP_OK;
 }
@@ -1056,9 +1138,12 @@ static void free_host_buffers(tphip_plan* p) {
     p->hostbuf = nullptr;
 }
 
-static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in, const int32_t* nres_in, double* rate,
-                    double* subst, double* lnl, uint8_t* flag, int32_t* nres, double* tables, bool do_site, bool do_pi) {
-    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+// Queues one host-pointer pass on the plan's own streams (no wait).  `spitch` = bytes between taxon rows of `states` at the
+// caller (= the plan's column count unless the plan is a locus group of a bigger batch); `after` = an event the upload must
+// wait for (the previous group's upload: the DMA engine serves one upload after the other, not all of them slowly).
+static int host_enqueue(tphip_plan* p, const uint8_t* states, size_t spitch, hipEvent_t after, const double* rates_in,
+                        const int32_t* nres_in, double* rate, double* subst, double* lnl, uint8_t* flag, int32_t* nres,
+                        double* tables, bool do_site, bool do_pi) {
     HIP_TRY(hipSetDevice(p->device));
     if (!p->hostbuf) {
         p->hostbuf = new tphip_host_buffers();
@@ -1086,7 +1171,10 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
         if (!states || !rate || !subst || !lnl || !flag || !nres) return fail(TPHIP_ERR_INVALID, "null host pointer");
         rc = grow((void**)&B.states, B.states_bytes, n * (size_t)p->ntaxa + 1);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(B.states, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice, rs));
+        if (after) HIP_TRY(hipStreamWaitEvent(rs, after, 0));
+        if (spitch == n) HIP_TRY(hipMemcpyAsync(B.states, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice, rs));
+        else HIP_TRY(hipMemcpy2DAsync(B.states, n, states, spitch, n, (size_t)p->ntaxa, hipMemcpyHostToDevice, rs));
+        HIP_TRY(hipEventRecord(B.ev_in, rs));
         rc = launch_site_rates(p, B.states, d_rate, d_subst, d_lnl, d_flag, d_nres, B.ws, rs, -1);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(B.ev_site, rs));
@@ -1115,9 +1203,51 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
         HIP_TRY(hipMemcpyAsync(nres, d_nres, sizeof(int32_t) * n, hipMemcpyDeviceToHost, os));
     }
     if (do_pi) HIP_TRY(hipMemcpyAsync(tables, B.tables, sizeof(double) * W * (size_t)p->nloci, hipMemcpyDeviceToHost, rs));
-    HIP_TRY(hipStreamSynchronize(rs));
-    HIP_TRY(hipStreamSynchronize(cs));
     return TPHIP_OK;
+}
+
+static int host_wait(tphip_plan* p) {
+    if (!p->hostbuf) return TPHIP_OK;
+    HIP_TRY(hipStreamSynchronize(p->hostbuf->run_stream));
+    HIP_TRY(hipStreamSynchronize(p->hostbuf->copy_stream));
+    return TPHIP_OK;
+}
+
+constexpr int64_t kHostSplitMinColumns = (int64_t)1 << 21;   // below this a pass is too short for the pipeline to pay
+
+static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in, const int32_t* nres_in, double* rate,
+                    double* subst, double* lnl, uint8_t* flag, int32_t* nres, double* tables, bool do_site, bool do_pi) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    // Big batches from pinned host memory: locus groups in a pipeline -- the upload of group k + 1 (and the download of group
+    // k - 1) run while group k computes.  Results do not depend on how a batch is cut (per-column results depend on the
+    // column and its locus' model only, a locus' PI row on its own columns in a fixed order).
+    const bool split = do_site && !p->is_part && p->saved && p->host_split > 1 && p->nloci >= 2 * p->host_split &&
+                       p->ncols >= kHostSplitMinColumns && states && rate && subst && lnl && flag && nres &&
+                       is_pinned(states) && is_pinned(rate) && is_pinned(subst) && is_pinned(lnl) && is_pinned(flag) &&
+                       is_pinned(nres) && (!do_pi || (tables && is_pinned(tables)));
+    if (!split) {
+        int rc = host_enqueue(p, states, (size_t)p->ncols, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables,
+                              do_site, do_pi);
+        if (rc) return rc;
+        return host_wait(p);
+    }
+    int rc = make_parts(p);
+    if (rc) return rc;
+    const size_t W = (size_t)tphip_plan_table_width(p);
+    hipEvent_t after = nullptr;
+    for (size_t k = 0; k < p->parts.size(); ++k) {
+        tphip_plan* q = p->parts[k];
+        const int64_t l0 = p->part_locus[k], c0 = p->h_offsets[l0];
+        rc = host_enqueue(q, states + c0, (size_t)p->ncols, after, nullptr, nullptr, rate + c0, subst + c0, lnl + c0, flag + c0,
+                          nres + c0, do_pi ? tables + (size_t)l0 * W : nullptr, true, do_pi);
+        if (rc) break;
+        after = q->hostbuf->ev_in;
+    }
+    for (tphip_plan* q : p->parts) {
+        const int rw = host_wait(q);
+        if (!rc) rc = rw;
+    }
+    return rc;
 }
 
 void* tphip_host_alloc(size_t bytes) {

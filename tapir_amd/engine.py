@@ -271,13 +271,14 @@ class Plan:
         return tables
 
     def run_fused(self, states, pinned=False):
-        """pinned=True: the result arrays live in pinned memory (direct DMA, copies overlapped with the PI kernels)."""
+        """pinned=True: the result arrays live in pinned memory (direct DMA, copies overlapped with the PI kernels; when
+        `states` is pinned too -- pinned_empty -- a big batch runs as a pipeline of locus groups, upload under compute)."""
         states = _np(states, np.uint8)
         assert states.shape == (self.ntaxa, self.ncols), (states.shape, self.ntaxa, self.ncols)
         n = self.ncols
         new = pinned_empty if pinned else np.empty
         out = dict(rate=new(n, np.float64), subst=new(n, np.float64), lnl=new(n, np.float64), flag=new(n, np.uint8),
-                   nres=new(n, np.int32), tables=np.empty((self.nloci, self.width)))
+                   nres=new(n, np.int32), tables=new((self.nloci, self.width), np.float64))
         _check(self._lib.tphip_run_fused(self._h, states.ctypes.data, out["rate"].ctypes.data, out["subst"].ctypes.data,
                                          out["lnl"].ctypes.data, out["flag"].ctypes.data, out["nres"].ctypes.data,
                                          out["tables"].ctypes.data))

@@ -793,6 +793,36 @@ def test_locus_loglik_vs_oracle(oracle):
         plan.close()
 
 
+def test_host_pointer_pipeline_of_locus_groups_is_bit_identical(monkeypatch):
+    """tphip_run_fused from pinned host memory cuts a big batch into locus groups (the upload of group k + 1 under the
+    kernels of group k); whatever the number of groups, ragged loci and an empty one included, every output must equal
+    the unsplit run's bit for bit -- and pageable buffers must take the plain path and agree too."""
+    engine = _engine()
+    from tapir_amd import synth
+    nloci, ncols, ntaxa = 40, 56000, 12
+    d = synth.simulate(nloci, ncols, ntaxa, 97)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    off = d["locus_offsets"].copy()
+    off[7] -= 1234                # ragged
+    off[20] = off[19]             # an empty locus
+    stp = engine.pinned_empty(st.shape, np.uint8)
+    stp[...] = st
+    outs = {}
+    for k in ("1", "3", "4", "9"):
+        monkeypatch.setenv("TPHIP_HOST_SPLIT", k)
+        plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, d["pi"], d["exch"], pin["T"], [3, 9], [[1, 8], [2, 20]],
+                           correction=pin["correction"])
+        outs[k] = plan.run_fused(stp, pinned=True)
+        if k == "4":
+            outs["pageable"] = plan.run_fused(st)
+        plan.close()
+    monkeypatch.delenv("TPHIP_HOST_SPLIT")
+    for k in ("3", "4", "9", "pageable"):
+        for key in outs["1"]:
+            assert np.array_equal(outs["1"][key], outs[k][key], equal_nan=True), (k, key)
+
+
 def _balanced_tree(levels, rng):
     """Post-order arrays of a perfectly balanced binary tree with 2**levels leaves: levels - 1 partials are parked at the
     deepest point.  The value kernel's register stack holds 5, so 6 levels = 64 leaves need all of them and 7 levels fall

@@ -36,3 +36,19 @@ for _ in range(n):
 dt3 = (time.perf_counter() - t0) / n
 print("  pinned buffers: %.1f ms per pass incl. allocating pinned result arrays; %.1f ms with the buffers reused, %.3g columns/s"
       % (dt2 * 1e3, dt3 * 1e3, st.shape[1] / dt3))
+
+# the pipeline of locus groups behind the pinned path, by number of groups (1 = off)
+for k in (1, 2, 3, 4, 6):
+    os.environ["TPHIP_HOST_SPLIT"] = str(k)
+    pk = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"], times,
+                     intervals, correction=pin["correction"])
+    out = pk.run_fused(stp, pinned=True)
+    for key in ref:
+        assert np.array_equal(ref[key], out[key], equal_nan=True), (k, key)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        engine._check(lib.tphip_run_fused(pk._h, stp.ctypes.data, out["rate"].ctypes.data, out["subst"].ctypes.data, out["lnl"].ctypes.data,
+                                          out["flag"].ctypes.data, out["nres"].ctypes.data, out["tables"].ctypes.data))
+    print("  %d locus group(s): %.1f ms per pass (bit-identical results)" % (k, (time.perf_counter() - t0) / n * 1e3))
+    pk.close()
+del os.environ["TPHIP_HOST_SPLIT"]
