@@ -92,6 +92,7 @@ struct tphip_plan {
     std::vector<int64_t> part_locus;         // [parts + 1] locus boundaries
     int32_t host_split = 1;
     bool is_part = false;
+    bool last_run_in_parts = false;
     int32_t device = 0;
     int32_t ntaxa = 0;
     int64_t nloci = 0, ncols = 0;
@@ -681,7 +682,15 @@ int tphip_last_eval_count(tphip_plan* p, int64_t* evals) {
     if (!p || !evals) return fail(TPHIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(p->device));
     unsigned long long v = 0;
-    HIP_TRY(hipMemcpy(&v, p->d_evals.p, sizeof v, hipMemcpyDeviceToHost));
+    if (p->last_run_in_parts) {   // the last site-rate launch was a host-pointer pipeline of locus groups: their sum
+        for (tphip_plan* q : p->parts) {
+            unsigned long long w = 0;
+            HIP_TRY(hipMemcpy(&w, q->d_evals.p, sizeof w, hipMemcpyDeviceToHost));
+            v += w;
+        }
+    } else {
+        HIP_TRY(hipMemcpy(&v, p->d_evals.p, sizeof v, hipMemcpyDeviceToHost));
+    }
     *evals = (int64_t)v;
     return TPHIP_OK;
 }
@@ -692,6 +701,7 @@ static PiParams pi_params(const tphip_plan* p, const double* d_rates, const int3
 
 static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_rate, double* d_subst, double* d_lnl,
                              uint8_t* d_flag, int32_t* d_nres, void* ws, hipStream_t st, int slot) {
+    p->last_run_in_parts = false;
     int32_t* work_cols = (int32_t*)((char*)ws + p->ws_work_cols);
     int32_t* work_count = (int32_t*)((char*)ws + p->ws_work_count);
     ClassifyParams C;
@@ -1234,6 +1244,7 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
     int rc = make_parts(p);
     if (rc) return rc;
     const size_t W = (size_t)tphip_plan_table_width(p);
+    p->last_run_in_parts = true;
     hipEvent_t after = nullptr;
     for (size_t k = 0; k < p->parts.size(); ++k) {
         tphip_plan* q = p->parts[k];
