@@ -13,16 +13,19 @@
 //   lik_pmat_kernel    thread = (candidate, node)  P_b = U exp(Lambda t_b) U^-1, stored transposed ([child state][parent
 //                                                  state]) so that the message of a resolved tip is one 32-byte row.
 //   locus_value_kernel workgroup = (candidate, column slice), thread = C columns
-//        tip      acc *= row x of P_b from an LDS copy of the candidate's tip matrices (2 ds_read_b128 + 4 multiplies;
-//                 ambiguity codes add the rows of their bits, a gap multiplies by 1 and is skipped); the thread's state
-//                 masks are packed 8 per word into thread-private LDS rows at the start of a column group, all loads in
-//                 flight together, instead of one memory round trip per tip op
-//        branch   acc  = P_b acc with P_b in SCALAR registers (one 128-byte scalar load per op and wave): 16 FP64
-//                 instructions per column instead of the 40 of the eigenbasis form U (e_b o U^T (pi o acc))
+//        tip      acc *= row x of P_b from an LDS copy of the candidate's tip matrices (2 ds_read_b128 + 4 multiplies).  Tip
+//                 states travel as 4-bit CODES (locus_value_params.hpp): 0..3 = the row of a resolved state, 4 = a row of ones
+//                 (gap / N: the row sums of P), 5..14 = the other IUPAC sets, which add the rows of their bits on a slow path
+//                 taken only by waves that hold one.  The thread's codes are packed 8 per word into thread-private LDS rows
+//                 at the start of a column group, 16 tips' loads in flight together, instead of one memory round trip per tip op
+//        branch   acc  = P_b acc with P_b in SCALAR registers (one 128-byte scalar load per op and wave, requested while the
+//                 op before it runs): 16 FP64 instructions per column instead of the 40 of the eigenbasis form
+//                 U (e_b o U^T (pi o acc)); the rescale test is 4 integer instructions on the exponent fields and a ballot
 //        parked siblings in REGISTERS (the stack depth D is a template parameter: 3 slots on a 64-taxon tree), so LDS holds
-//        only the tip matrices and mask words and 5+ waves per SIMD hide the scalar-load and LDS latencies
+//        only the tip matrices and code words and occupancy is set by registers (111 VGPRs for C = 2, D = 3: 4 waves per SIMD)
 //        op stream: TIP_SET + TIP_MUL pairs fused into CHERRY, PUSH / POP_MUL riding as flags on their neighbours
-//        (105 interpreter iterations instead of 189 on 64 taxa), decoded once for the thread's C columns.
+//        (105 interpreter iterations instead of 189 on 64 taxa), every field precomputed in the 16-byte record, records
+//        fetched two ahead, decoded once for the thread's C columns.
 //
 // Bound: FP64 VALU, ~24 ntaxa useful instructions per column and candidate (the eigenbasis kernel: ~83 ntaxa).  The
 // matrices cost nnodes * 128 B per candidate of workspace, written once and read once per wave and column group:
