@@ -12,7 +12,7 @@
 
 #include "gtr_model.hpp"
 #include "gtr_setup_kernel.hpp"
-#include "locus_lik_kernel.hpp"
+#include "locus_lik_params.hpp"
 #include "locus_value_params.hpp"
 #include "pattern_kernels.hpp"
 #include <hipcub/hipcub.hpp>
@@ -505,7 +505,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         if (p->lik_stage) p->lik_lds += lik_stage_bytes;
         p->lik_ok = p->lik_lds <= 150 * 1024;
         if (p->lik_ok && p->lik_lds > 64 * 1024)
-            p->lik_ok = hipFuncSetAttribute((const void*)locus_loglik_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+            p->lik_ok = locus_loglik_kernel_allow_lds(150 * 1024) == hipSuccess;
         // value kernel on transition matrices (locus_value_kernel.hpp): C columns per thread share the op decode and the
         // scalar loads of a branch's matrix; parked siblings live in registers (template depth), LDS holds the tip matrices
         // and the packed state masks
@@ -532,10 +532,10 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         if (p->grad_stage) p->grad_lds += grad_stage_bytes;
         p->grad_ok = p->grad_lds <= 150 * 1024;
         if (p->grad_ok && p->grad_lds > 64 * 1024)
-            p->grad_ok = hipFuncSetAttribute((const void*)locus_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+            p->grad_ok = locus_grad_kernel_allow_lds(150 * 1024) == hipSuccess;
         if (p->grad_ok) {
             int bpc = 1;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, locus_grad_kernel, kGradBlock, p->grad_lds) != hipSuccess || bpc < 1) bpc = 1;
+            if (locus_grad_kernel_occupancy(p->grad_lds, &bpc) != hipSuccess || bpc < 1) bpc = 1;
             // the tape of the resident blocks should stay within reach of the 256 MB memory-side cache: with 64 taxa, 4
             // blocks per CU (390 MB of tape) ran slower than 3 (91 vs 85 ms); fewer than 3 loses more to latency
             const size_t tape_per_block = (size_t)std::max(1, p->prog.ntape + p->prog.stack_depth) * 4 * kGradBlock * sizeof(double);
@@ -985,8 +985,7 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
         }
         HIP_TRY(hipGetLastError());
         if (nsplit > 1) {
-            split_sum_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st>>>(p->d_part, d_out, ncand, nsplit, 1);
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(launch_split_sum_kernel(st, p->d_part, d_out, ncand, nsplit, 1));
         }
         return TPHIP_OK;
     }
@@ -1006,12 +1005,11 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
         LikParams Q = L;
         Q.cand_locus += done; Q.cand_exch += done * 6; Q.cand_vec += done; Q.cand_scale += done; Q.cand_pidx += done;
         Q.cand_pfac += done; Q.out += done * nsplit;
-        locus_loglik_kernel<<<dim3((unsigned)(n * nsplit)), dim3(kLikBlock), lds, (hipStream_t)stream>>>(Q);
+        HIP_TRY(launch_locus_loglik_kernel(dim3((unsigned)(n * nsplit)), lds, (hipStream_t)stream, Q));
     }
     HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
-        split_sum_kernel<<<dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(p->d_part, d_out, ncand, nsplit, 1);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_split_sum_kernel((hipStream_t)stream, p->d_part, d_out, ncand, nsplit, 1));
     }
     return TPHIP_OK;
 }
@@ -1074,12 +1072,10 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
     }
     if (!p->d_grad_params) HIP_TRY(hipMalloc((void**)&p->d_grad_params, sizeof(GradParams)));
     HIP_TRY(hipMemcpyAsync(p->d_grad_params, &G, sizeof(GradParams), hipMemcpyHostToDevice, (hipStream_t)stream));
-    locus_grad_kernel<<<dim3((unsigned)grid), dim3(kGradBlock), lds, (hipStream_t)stream>>>((const GradParams*)p->d_grad_params);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_locus_grad_kernel(dim3((unsigned)grid), lds, (hipStream_t)stream, (const GradParams*)p->d_grad_params));
     if (nsplit > 1) {
         auto sum = [&](const double* part, double* out, int width) {
-            const int64_t n = ncand * width;
-            split_sum_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(part, out, ncand, nsplit, width);
+            (void)launch_split_sum_kernel((hipStream_t)stream, part, out, ncand, nsplit, width);
         };
         sum(L.out, d_lnl, 1);
         sum(G.out_sum_dlogt, d_sum_dlogt, 1);
