@@ -78,6 +78,22 @@ __global__ __launch_bounds__(128) void lik_pmat_kernel(const double* eig, const 
         }
 }
 
+// packed[w][col] = the state codes of tips 8w .. 8w+7 (program order) of column col, 4 bits each
+__global__ __launch_bounds__(256) void value_pack_codes_kernel(const uint8_t* states, int64_t ncols_total, const int32_t* tip_taxon,
+                                                               int32_t nwords, uint32_t* packed) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols_total) return;
+    for (int w = 0; w < nwords; ++w) {
+        unsigned word = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned m = states[(int64_t)tip_taxon[w * 8 + q] * ncols_total + col] & 15u;
+            word |= (unsigned)((kValueCodeOfMask >> (4 * m)) & 15ull) << (4 * q);
+        }
+        packed[(size_t)w * ncols_total + col] = word;
+    }
+}
+
 typedef const double __attribute__((address_space(4)))* value_cptr;   // constant address space: wave-uniform reads become scalar loads
 
 template <int C, int D>
@@ -133,26 +149,34 @@ __global__ __launch_bounds__(kLikBlock) void locus_value_kernel(ValueParams P) {
             for (int c = 0; c < C; ++c)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) stk[d][c][i] = 1.0;
-        // The thread's state masks, in tip order, 8 four-bit masks per word (thread-private rows of LDS: no barrier).  All
-        // loads of two words are in flight together.
-        for (int w0 = 0; w0 < P.nwords; w0 += 2) {
-            unsigned b[C][16];
+        // The thread's state codes, in tip order, 8 per word, into thread-private rows of LDS (no barrier): from the array
+        // packed at upload time when there is one (one dword per 8 tips), else from the state bytes with the loads of two
+        // words in flight together.
+        if (P.packed) {
+#pragma unroll 4
+            for (int w = 0; w < P.nwords; ++w)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int j = w0 * 8 + q;
-                const int taxon = P.tip_taxon[j < P.nwords * 8 ? j : 0];
+                for (int c = 0; c < C; ++c) msk[((size_t)w * C + c) * kLikBlock + threadIdx.x] = P.packed[(size_t)w * P.ncols_total + col[c]];
+        } else {
+            for (int w0 = 0; w0 < P.nwords; w0 += 2) {
+                unsigned b[C][16];
 #pragma unroll
-                for (int c = 0; c < C; ++c) b[c][q] = P.states[(int64_t)taxon * P.ncols_total + col[c]];
-            }
+                for (int q = 0; q < 16; ++q) {
+                    const int j = w0 * 8 + q;
+                    const int taxon = P.tip_taxon[j < P.nwords * 8 ? j : 0];
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
+                    for (int c = 0; c < C; ++c) b[c][q] = P.states[(int64_t)taxon * P.ncols_total + col[c]];
+                }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    unsigned word = 0;
+                for (int c = 0; c < C; ++c) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        word |= (unsigned)((kValueCodeOfMask >> (4 * (b[c][h * 8 + q] & 15u))) & 15ull) << (4 * q);
-                    if (w0 + h < P.nwords) msk[((size_t)(w0 + h) * C + c) * kLikBlock + threadIdx.x] = word;
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned word = 0;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            word |= (unsigned)((kValueCodeOfMask >> (4 * (b[c][h * 8 + q] & 15u))) & 15ull) << (4 * q);
+                        if (w0 + h < P.nwords) msk[((size_t)(w0 + h) * C + c) * kLikBlock + threadIdx.x] = word;
+                    }
                 }
             }
         }

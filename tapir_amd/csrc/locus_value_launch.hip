@@ -34,6 +34,13 @@ hipError_t locus_value_kernel_allow_lds(int cols, int depth, size_t lds_bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
+hipError_t launch_value_pack_codes_kernel(hipStream_t st, const uint8_t* states, int64_t ncols_total, const int32_t* tip_taxon,
+                                         int32_t nwords, uint32_t* packed) {
+    if (ncols_total <= 0) return hipSuccess;
+    value_pack_codes_kernel<<<dim3((unsigned)((ncols_total + 255) / 256)), dim3(256), 0, st>>>(states, ncols_total, tip_taxon, nwords, packed);
+    return hipGetLastError();
+}
+
 hipError_t launch_lik_eigen_kernel(hipStream_t st, const LocusModel* models, const int32_t* cand_locus, const double* cand_exch,
                                    int64_t ncand, double* eig_out) {
     lik_eigen_kernel<<<dim3((unsigned)((ncand + 63) / 64)), dim3(64), 0, st>>>(models, cand_locus, cand_exch, ncand, eig_out);

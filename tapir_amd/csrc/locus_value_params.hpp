@@ -30,6 +30,9 @@ struct ValueParams {
     const int4* vops;
     const int32_t* tip_taxon;      // taxon of the j-th tip, in op order, padded to a multiple of 8
     const int32_t* tip_node;       // [ntaxa] tree node of the taxon's tip (-1: the taxon is not in the tree)
+    const uint32_t* packed;        // [nwords][ncols_total] the same state codes, 8 per word in tip order, packed once when the
+                                   // library uploaded the alignment itself (value_pack_codes_kernel); null: the kernel packs
+                                   // its columns from `states` at the start of every column group
     int32_t nvops, ntaxa, nnodes, nwords;
     const int32_t* cand_locus;     // [ncand of this launch]
     const double* pmat;            // [ncand of this launch][nnodes][16]
@@ -42,6 +45,8 @@ constexpr int kValueMaxDepth = 5;   // deepest register stack instantiated (a Se
 // host side of the value kernels (locus_value_launch.hip)
 hipError_t launch_locus_value_kernel(int cols, int depth, dim3 grid, size_t lds_bytes, hipStream_t st, const ValueParams& V);
 hipError_t locus_value_kernel_allow_lds(int cols, int depth, size_t lds_bytes);
+hipError_t launch_value_pack_codes_kernel(hipStream_t st, const uint8_t* states, int64_t ncols_total, const int32_t* tip_taxon,
+                                         int32_t nwords, uint32_t* packed);
 hipError_t launch_lik_eigen_kernel(hipStream_t st, const LocusModel* models, const int32_t* cand_locus, const double* cand_exch,
                                    int64_t ncand, double* eig_out);
 hipError_t launch_lik_pmat_kernel(hipStream_t st, const double* eig, const double* blen_vecs, const int32_t* cand_vec,

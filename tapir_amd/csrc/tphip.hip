@@ -120,6 +120,8 @@ struct tphip_plan {
     size_t grad_eig_bytes = 0;
     double* d_value_ws = nullptr;   // per-candidate eigen-systems + transition matrices of locus_value_kernel (one chunk)
     size_t value_ws_bytes = 0;
+    const uint8_t* lib_states = nullptr;   // the device copy of the alignment the library made itself (stage_alignment) ...
+    uint32_t* d_value_packed = nullptr;    // ... and its state codes packed for locus_value_kernel (valid for exactly that copy)
     int32_t value_cols = 0;         // columns per thread of locus_value_kernel (0: tree too large for it, eigenbasis kernel instead)
     size_t value_lds = 0;
     DevBuf<int4> d_value_ops;       // fused op stream of locus_value_kernel
@@ -188,6 +190,7 @@ int tphip_plan_destroy(tphip_plan* plan) {
     if (plan->d_tape) { (void)hipFree(plan->d_tape); plan->d_tape = nullptr; }
     if (plan->d_value_ws) { (void)hipFree(plan->d_value_ws); plan->d_value_ws = nullptr; }
     if (plan->d_grad_eig) { (void)hipFree(plan->d_grad_eig); plan->d_grad_eig = nullptr; }
+    if (plan->d_value_packed) { (void)hipFree(plan->d_value_packed); plan->d_value_packed = nullptr; }
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
     if (plan->d_grad_params) { (void)hipFree(plan->d_grad_params); plan->d_grad_params = nullptr; }
@@ -973,6 +976,7 @@ int tphip_locus_loglik_dev(tphip_plan* p, const uint8_t* d_states, int64_t ncand
         V.models = p->d_models.p; V.vops = p->d_value_ops.p; V.nvops = p->value_nops; V.ntaxa = p->ntaxa;
         V.nnodes = p->nnodes; V.pmat = d_pmat; V.nsplit = nsplit;
         V.tip_taxon = p->d_tip_taxon.p; V.nwords = p->nwords; V.tip_node = p->d_value_tip_node.p;
+        V.packed = (d_states == p->lib_states) ? p->d_value_packed : nullptr;
         hipStream_t st = (hipStream_t)stream;
         for (int64_t done = 0; done < ncand; done += chunk) {
             const int64_t n = std::min<int64_t>(ncand - done, chunk);
@@ -1377,6 +1381,10 @@ int tphip_plan_set_column_weights(tphip_plan* p, const double* weights) {
 int tphip_free_device(tphip_plan* p, void* d_ptr) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
     HIP_TRY(hipSetDevice(p->device));
+    if (d_ptr && d_ptr == (void*)p->lib_states) {   // the alignment cache goes: so do the codes packed from it
+        if (p->d_value_packed) { HIP_TRY(hipFree(p->d_value_packed)); p->d_value_packed = nullptr; }
+        p->lib_states = nullptr;
+    }
     if (d_ptr) HIP_TRY(hipFree(d_ptr));
     return TPHIP_OK;
 }
@@ -1423,6 +1431,16 @@ int stage_alignment(tphip_plan* p, const uint8_t* states, void** d_states_cache,
         if (!*d_s) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
     }
     HIP_TRY(hipMemcpy(*d_s, states, nb, hipMemcpyHostToDevice));
+    if (d_states_cache && p->value_cols > 0 && p->ncols > 0) {
+        // a copy that stays: pack its state codes once for locus_value_kernel (8 per word, tip order) instead of once per
+        // likelihood evaluation.  Only for the copy made here -- the library cannot know when a caller's own device array changes.
+        if (p->d_value_packed) { HIP_TRY(hipFree(p->d_value_packed)); p->d_value_packed = nullptr; }
+        p->lib_states = nullptr;
+        HIP_TRY(hipMalloc((void**)&p->d_value_packed, sizeof(uint32_t) * (size_t)p->nwords * (size_t)p->ncols));
+        HIP_TRY(launch_value_pack_codes_kernel(nullptr, *d_s, p->ncols, p->d_tip_taxon.p, p->nwords, p->d_value_packed));
+        HIP_TRY(hipStreamSynchronize(nullptr));   // later launches may come on any stream
+        p->lib_states = *d_s;
+    }
     return TPHIP_OK;
 }
 

@@ -880,6 +880,9 @@ def test_locus_value_kernel_codes_trees_and_widths(oracle, monkeypatch):
                 monkeypatch.setenv("TPHIP_VALUE_COLS", variant)
             plan = engine.Plan(ntaxa, parent, blen, leaf, off, pi, np.ones((nloci, 6)), 3, [1], [[0, 1]])
             plain = plan.locus_loglik(st, cb, cl, ce)
+            cache = plan.device_cache()      # the library's own device copy: state codes packed once at upload
+            assert np.array_equal(plain, plan.locus_loglik(st, cb, cl, ce, cache=cache)), (levels, variant)
+            cache.release()
             plan.set_column_weights(w)
             results[variant] = (plain, plan.locus_loglik(st, cb, cl, ce))
             plan.close()
