@@ -26,7 +26,8 @@
  *
  * Optimiser policy (HyPhy's own derivative-free optimiser is not reproducible):
  *   maximise f(u) = log L(exp(u)) from the column's parsimony rate (fitch_start; HyPhy: s=1) with a safeguarded
- *   Newton iteration that follows the uphill direction to the nearest local maximum.  Flags: 0 interior optimum, 1 flat (<=1 resolved
+ *   Newton iteration that follows the uphill direction to the nearest local maximum (on trees of 32 taxa or more the
+ *   first step also uses the column's parsimony length, the slope of f as u -> -inf; maximise_column).  Flags: 0 interior optimum, 1 flat (<=1 resolved
  *   taxon: L does not depend on s, s stays 1), 2 saturated (log L flat to fp64 resolution on the way to
  *   s -> infinity, or still uphill at s = 1e4: s = 1e4 is reported), 3 optimum at s = 0 (all resolved
  *   taxa carry the same base), 4 iteration limit.
@@ -63,6 +64,7 @@
 #else
 #define ORC_HERMITE_SPAN 2e-4
 #endif
+#define ORC_FIRST_STEP_MIN_TAXA 32 /* trees from this size on use the parsimony length in the first step (same constant as the engine) */
 #define ORC_FLAT_EPS 1e-10 /* |dlogL/du| and |d2logL/du2| below this: surface flat to fp64 -> saturated */
 
 /* ------------------------------------------------------------------------------------------------
@@ -671,7 +673,7 @@ static void fitch_child_order(const orc_tree *tr, int **kids_out, int **first_ou
  * e^3 away from the optimum; the maximum reached is the same, in fewer evaluations.)  Sets are 4-bit masks; a node's
  * children are joined one after the other in the order of fitch_child_order. */
 static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kids, const int *first, const uint8_t *states,
-                          int64_t ncols, int64_t col, double chrono, int resolved) {
+                          int64_t ncols, int64_t col, double chrono, int resolved, int *changes_out) {
     unsigned char *set = (unsigned char *)malloc((size_t)tr->nnodes);
     int changes = 0;
     for (int n = 0; n < tr->nnodes; ++n) { /* post-order: a node's children are complete when it is reached */
@@ -688,6 +690,7 @@ static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kid
         set[n] = (unsigned char)s;
     }
     free(set);
+    *changes_out = changes;
     const double len = m->kappa * chrono * ((double)(resolved > 0 ? resolved : 1) / (double)tr->ntaxa);
     /* parsimony undercounts where changes are dense: stretch the count with p = changes per branch among the taxa
      * present, m' = B (-a ln(1 - p/a)), a = 0.30, p capped at 0.28 (same constants as classify_kernel) */
@@ -703,8 +706,9 @@ static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kid
 }
 
 /* Safeguarded Newton on u = log s from u_start, to the local maximum uphill of the start. */
+/* mfitch: the column's parsimony length when the start is the parsimony start (used by the first step), else 0 */
 static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
-                            double u_start, double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
+                            double u_start, double mfitch, double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
     double u = u_start, lo = ORC_U_MIN, hi = ORC_U_MAX, f = 0, g, h;
     double u_prev = 0, h_prev = 0, g_prev = 0;
     int lo_open = 1, hi_open = 1, have_prev = 0; /* bracket ends not evaluated yet; previous point known */
@@ -732,6 +736,15 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
         if (h < 0) {
             const double q = 1.0 - g / h;
             step = (q > 0) ? log(q) : -g / h;
+            /* First step from the parsimony start: as u -> -inf the slope of log L tends to the column's parsimony length m.
+             * Fitting m u - a exp(b u) + c to (m, g, h) -- one more shape parameter than the model above, whose m is implied
+             * by g - h -- gives (1/b) log(m / (m - g)), b = -h / (m - g): nearer the optimum than the step above on 99 % of
+             * columns (tools/debug/step_rule_experiment.py), 3-5 % fewer evaluations; same rule as site_rate_kernel. */
+            if (!have_prev && mfitch > 0.0) {
+                const double A = mfitch - g;
+                const double sb = (A > 0.0) ? log(mfitch / A) * (A / -h) : ORC_STEP_MAX + 1.0;
+                if (fabs(sb) <= ORC_STEP_MAX) step = sb;
+            }
         } else {
             step = uphill ? ORC_STEP_MAX : -ORC_STEP_MAX;
         }
@@ -900,9 +913,11 @@ static int64_t site_rates_impl(const uint8_t *states, int64_t ncols, int32_t nta
         } else if (start_mode == 1) {
             maximise_column_plain(&m, &tr, states, ncols, c, &s, &f, &fl, &ne);
         } else if (start_mode == 2) { /* HyPhy's start value, the product's step rule and exits (tphip_plan_desc.start_rule = 1) */
-            maximise_column(&m, &tr, states, ncols, c, 0.0, &s, &f, &fl, &ne);
+            maximise_column(&m, &tr, states, ncols, c, 0.0, 0.0, &s, &f, &fl, &ne);
         } else {
-            maximise_column(&m, &tr, states, ncols, c, fitch_start(&m, &tr, kids, first, states, ncols, c, chrono, resolved), &s, &f, &fl, &ne);
+            int changes = 0;
+            const double u0 = fitch_start(&m, &tr, kids, first, states, ncols, c, chrono, resolved, &changes);
+            maximise_column(&m, &tr, states, ncols, c, u0, ntaxa >= ORC_FIRST_STEP_MIN_TAXA ? (double)changes : 0.0, &s, &f, &fl, &ne);
         }
         total_eval += ne;
         rate[c] = s * m.kappa;

@@ -16,6 +16,7 @@
 #include "gtr_model.hpp"
 #include "tree_program.hpp"
 #include "quadpack_device.hpp"
+#include "site_rate_params.hpp"
 #include "tphip.h"
 
 namespace tphip {
@@ -184,6 +185,10 @@ __device__ __forceinline__ void classify_finish(const ClassifyParams& P, const L
         // u0 for site_rate_kernel, which overwrites it with the answer: the parsimony start, or u = log 1 = 0 when the
         // plan asks for HyPhy's start value (start_scale = 0; a multiplication, not a branch: + 0.0 turns -0.0 into 0.0)
         P.rate[col] = start_log_rate(P, M, c) * P.start_scale + 0.0;
+        // the column's parsimony length for the optimiser's first step (site_rate_kernel overwrites the slot with the answer);
+        // 0 = none: HyPhy's start value asks for the plain step from there, and on small trees an evaluation is so cheap that
+        // the extra logarithm costs more than the saved evaluations (C2, 16 taxa: +4 % time with it; C3 -2 %, C5 -4 %)
+        P.subst[col] = (P.ntaxa >= kFirstStepMinTaxa) ? (double)c.changes * P.start_scale : 0.0;
     }
 }
 

@@ -9,6 +9,7 @@
 
 namespace tphip {
 
+constexpr int kFirstStepMinTaxa = 32;   // trees from this size on use the parsimony length in the optimiser's first step (pi_kernels.hpp)
 constexpr double kUMin = -23.025850929940457;  // log(1e-10)
 constexpr double kUMax = 9.210340371976184;    // log(1e4)
 constexpr double kStepMax = 2.0;
