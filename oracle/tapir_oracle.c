@@ -59,11 +59,17 @@
 #define ORC_U_CHECK 2.995732273553991 /* log(20): optima beyond this rate are confirmed by value, see maximise_column */
 #define ORC_SAT_TOL 1e-10
 #ifndef ORC_HERMITE_TOL /* 0 switches the rule off (accuracy experiments against a tight reference) */
-#define ORC_HERMITE_SPAN 2e-4 /* ... and only while |step| * |distance between the two points| stays below this */
-#define ORC_HERMITE_TOL 1e-3 /* final step from the two-point Hermite model of f' accepted below this size */
+#define ORC_HERMITE_SPAN 3e-4 /* ... and only while |step| * |distance between the two points| stays below this */
+#define ORC_HERMITE_TOL 2e-3 /* final step from the two-point quartic model of f' accepted below this size */
 #else
-#define ORC_HERMITE_SPAN 2e-4
+#define ORC_HERMITE_SPAN 3e-4
 #endif
+#define ORC_HERMITE_T2D3 1.5e-8    /* step^2 * |distance of the far point|^3 below this (the quartic's error term) */
+#define ORC_HERMITE_GUARD 0.005    /* the quartic's higher-order terms at the step, relative to |h| (the cubic path: 0.02) */
+#define ORC_HERMITE_REGULAR 0.1    /* curvature |h| at both points from which the quartic (value difference included) is used */
+#define ORC_HERMITE_TOL_WEAK 1e-3  /* below that curvature: the cubic through the slopes with round 1's bounds */
+#define ORC_HERMITE_SPAN_WEAK 2e-4
+#define ORC_HERMITE_NOISE 5.3e-5 /* 30 * (8 * 2.2e-16) / 1e-9, see maximise_column */
 #define ORC_FIRST_STEP_MIN_TAXA 32 /* trees from this size on use the parsimony length in the first step (same constant as the engine) */
 #define ORC_FLAT_EPS 1e-10 /* |dlogL/du| and |d2logL/du2| below this: surface flat to fp64 -> saturated */
 
@@ -710,7 +716,7 @@ static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kid
 static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_t *states, int64_t ncols, int64_t col,
                             double u_start, double mfitch, double *s_out, double *f_out, uint8_t *flag_out, int32_t *neval) {
     double u = u_start, lo = ORC_U_MIN, hi = ORC_U_MAX, f = 0, g, h;
-    double u_prev = 0, h_prev = 0, g_prev = 0;
+    double u_prev = 0, h_prev = 0, g_prev = 0, f_prev = 0;
     int lo_open = 1, hi_open = 1, have_prev = 0; /* bracket ends not evaluated yet; previous point known */
     *flag_out = 4;
     for (int it = 0; it < ORC_MAXIT; ++it) {
@@ -756,25 +762,54 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
          * of at least ORC_PLATEAU_STRIDE covers the two log-units to flatness in a few evaluations; a maximum that does
          * lie ahead is overshot by at most that much and then bracketed from both sides. */
         if (uphill && hi_open && u >= ORC_U_CHECK && step < ORC_PLATEAU_STRIDE) step = ORC_PLATEAU_STRIDE;
-        /* With two evaluations in hand, f' is known with its slope at both points: the cubic Hermite interpolant of f'
-         * through (u_prev, g_prev, h_prev) and (u, g, h) locates the zero to fourth order, so a remaining step of up to
-         * 1e-3 can be taken WITHOUT evaluating again (at 2e-3 the worst residual over 8e5 columns reached 1.2e-6; the
-         * third-order correction below needs the step under 3e-4 for that).  One evaluation in nine saved. */
+        /* With two evaluations in hand, f' is known with its slope at both points, and so is its integral between them
+         * (the difference of the two values): the quartic through those five conditions locates the zero of f' to fifth
+         * order, so a remaining step of up to ORC_HERMITE_TOL can be taken WITHOUT evaluating again.  (Round 1 used the
+         * cubic through the four slope conditions: ~15 x the error at the same step, hence bounds of 1e-3 / 2e-4 and 60 % of
+         * the columns leaving after two evaluations; DESIGN section 8 r2 has the calibration of the present bounds.)
+         * The quartic is for REGULAR points only -- curvature of at least ORC_HERMITE_REGULAR at both, i.e. a tenth of a
+         * substitution's worth (|h| ~ the number of changes at the optimum of a regular column).  A weakly curved column
+         * (near an inflection or a plateau) keeps round 1's cubic and bounds: there the value difference made things
+         * worse (1.1e-6 instead of 2e-8 on one column in 27 000 of a 16-taxon set). */
         if (have_prev && h < 0) {
-            const double d = u - u_prev;
-            const double c3 = 2.0 * (g_prev - g) / (d * d * d) + (h + h_prev) / (d * d);
-            const double c2 = (h - h_prev) / (2.0 * d) + 1.5 * c3 * d;
+            const double d = u - u_prev; /* the previous point sits at t = -d */
+            const int regular = fabs(h) >= ORC_HERMITE_REGULAR && fabs(h_prev) >= ORC_HERMITE_REGULAR;
+            double q2, q3, q4 = 0.0;
+            if (regular) {
+                const double r1 = g_prev - g + h * d, r2 = (h_prev - h) * d, r3 = (f - f_prev) / d - g + 0.5 * h * d;
+                const double id = 1.0 / d, id2 = id * id;
+                q2 = (-12.0 * r1 - 1.5 * r2 + 30.0 * r3) * id2;
+                q3 = (-28.0 * r1 - 4.0 * r2 + 60.0 * r3) * (id2 * id);
+                q4 = (-15.0 * r1 - 2.5 * r2 + 30.0 * r3) * (id2 * id2);
+            } else {
+                q3 = 2.0 * (g_prev - g) / (d * d * d) + (h + h_prev) / (d * d);
+                q2 = (h - h_prev) / (2.0 * d) + 1.5 * q3 * d;
+            }
             double t = -g / h;
-            for (int k = 0; k < 3; ++k) { /* Newton on the cubic g + h t + c2 t^2 + c3 t^3 */
-                const double p = g + t * (h + t * (c2 + t * c3)), dp = h + t * (2.0 * c2 + 3.0 * t * c3);
+            for (int k = 0; k < 4; ++k) { /* Newton on g + h t + q2 t^2 + q3 t^3 + q4 t^4 */
+                const double p = g + t * (h + t * (q2 + t * (q3 + t * q4)));
+                const double dp = h + t * (2.0 * q2 + t * (3.0 * q3 + 4.0 * t * q4));
                 if (dp < 0) t -= p / dp;
             }
-            /* the interpolation error grows like (d t)^2: a far-away first point must not vouch for the step */
+            const double tol2 = regular ? ORC_HERMITE_TOL : ORC_HERMITE_TOL_WEAK, span2 = regular ? ORC_HERMITE_SPAN : ORC_HERMITE_SPAN_WEAK;
+            /* The quartic is the derivative of the quintic Hermite interpolant of f (three conditions at each point), whose
+             * error is f^(6) / 6! t^3 (t + d)^3: the zero of f' is off by K t^2 |d|^3 with K = |f^(6)| / (240 |h|), hence a
+             * bound on t^2 |d|^3 itself.  K is ~0.004 on the median column, ~15 on fast sites whose series in u has a radius
+             * of ~0.4 -- and reaches 300 on the wildest of C4's and C5's 57 M optimised columns (curvature halving within 0.1
+             * log-units: one in 10^7), where only a small step helps: the error is what the model gets wrong in the third
+             * derivative times t^2 / |h|, up to ~t^2 / 30.  Wider bounds were measured (step 1e-2, span 1e-3: 87 % of the
+             * columns leave after two evaluations instead of 67 %) and left 1.1e-6 on one column of C5; an agreement test
+             * between the quartic and the cubic does not catch those columns -- both interpolants are off by the same amount. */
+            const int t2d3_ok = !regular || t * t * fabs(d * d * d) < ORC_HERMITE_T2D3;
+            /* the interpolation error grows with the distance to the far point: it must not vouch for the step ... */
             /* ... and where the curvature is weak compared with the higher-order terms (a nearly flat column) the zero
-             * of f' is too sensitive to the model: the quadratic and cubic terms must be a small correction of h */
-            if (fabs(t) < ORC_HERMITE_TOL && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < ORC_HERMITE_SPAN &&
-                fabs(t * (c2 + t * c3)) < 0.02 * fabs(h)) {
-                f += t * (g + t * (0.5 * h + t * (c2 / 3.0 + t * (c3 / 4.0))));
+             * of f' is too sensitive to the model: those terms must be a small correction of h */
+            /* ... and the difference of two rounded values must not steer the zero: the rounding of f reaches q2 as
+             * ~30 eps |f| / |d|^3 and moves the zero by that times t^2 / |h|, kept below 1e-9 */
+            if (t2d3_ok && fabs(t) < tol2 && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < span2 &&
+                fabs(t * (q2 + t * (q3 + t * q4))) < (regular ? ORC_HERMITE_GUARD : 0.02) * fabs(h) &&
+                (!regular || ORC_HERMITE_NOISE * fabs(f) * (t * t) < fabs(h) * fabs(d * d * d))) {
+                f += t * (g + t * (0.5 * h + t * (q2 / 3.0 + t * (0.25 * q3 + t * (0.2 * q4)))));
                 u += t;
                 *flag_out = 0;
                 if (u >= ORC_U_CHECK) { /* same confirmation by value as below */
@@ -819,7 +854,7 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
             }
             break;
         }
-        u_prev = u; h_prev = h; g_prev = g; have_prev = 1;
+        u_prev = u; h_prev = h; g_prev = g; f_prev = f; have_prev = 1;
         u = un;
     }
     *s_out = exp(u);

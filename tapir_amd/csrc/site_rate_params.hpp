@@ -14,8 +14,14 @@ constexpr double kUMin = -23.025850929940457;  // log(1e-10)
 constexpr double kUMax = 9.210340371976184;    // log(1e4)
 constexpr double kStepMax = 2.0;
 constexpr double kStepTol = 3e-4;       // accept when the step is this small: applied with a third-order correction
-constexpr double kHermiteSpan = 2e-4;   // ... while |step| * |distance between the two points| stays below this
-constexpr double kHermiteTol = 1e-3;    // final step from the two-point Hermite model of f' accepted below this size
+constexpr double kHermiteSpan = 3e-4;   // ... while |step| * |distance between the two points| stays below this
+constexpr double kHermiteTol = 2e-3;    // final step from the two-point quartic model of f' accepted below this size
+                                        // (calibration of the two bounds: tools/debug/two_point_experiment.py)
+constexpr double kHermiteT2D3 = 1.5e-8;  // step^2 * |distance of the far point|^3 below this (the quartic's error term)
+constexpr double kHermiteGuard = 0.005;  // the quartic's higher-order terms at the step, relative to |h| (the cubic path: 0.02)
+constexpr double kHermiteRegular = 0.1;  // curvature |h| at both points from which the quartic is used; below: the cubic with ...
+constexpr double kHermiteTolWeak = 1e-3, kHermiteSpanWeak = 2e-4;   // ... round 1's bounds
+constexpr double kHermiteNoise = 5.3e-5; // 30 * (8 * 2.2e-16) / 1e-9: rounding of the two values vs curvature (site_rate_kernel.hpp)
 constexpr double kStepTolFirst = 1e-6;  // ... except at the first evaluation (no second point yet)
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
