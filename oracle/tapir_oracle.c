@@ -65,10 +65,8 @@
 #define ORC_HERMITE_SPAN 3e-4
 #endif
 #define ORC_HERMITE_T2D3 1.5e-8    /* step^2 * |distance of the far point|^3 below this (the quartic's error term) */
-#define ORC_HERMITE_GUARD 0.005    /* the quartic's higher-order terms at the step, relative to |h| (the cubic path: 0.02) */
-#define ORC_HERMITE_REGULAR 0.1    /* curvature |h| at both points from which the quartic (value difference included) is used */
-#define ORC_HERMITE_TOL_WEAK 1e-3  /* below that curvature: the cubic through the slopes with round 1's bounds */
-#define ORC_HERMITE_SPAN_WEAK 2e-4
+#define ORC_HERMITE_GUARD 0.005    /* the quartic's higher-order terms at the step, relative to |h| */
+#define ORC_HERMITE_REGULAR 0.25   /* curvature |h| from which the two exits apply (below: iterate until the step is below 1e-6) */
 #define ORC_HERMITE_NOISE 5.3e-5 /* 30 * (8 * 2.2e-16) / 1e-9, see maximise_column */
 #define ORC_FIRST_STEP_MIN_TAXA 32 /* trees from this size on use the parsimony length in the first step (same constant as the engine) */
 #define ORC_FLAT_EPS 1e-10 /* |dlogL/du| and |d2logL/du2| below this: surface flat to fp64 -> saturated */
@@ -682,10 +680,12 @@ static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kid
                           int64_t ncols, int64_t col, double chrono, int resolved, int *changes_out) {
     unsigned char *set = (unsigned char *)malloc((size_t)tr->nnodes);
     int changes = 0;
+    int base_count[4] = {0, 0, 0, 0}; /* plain A / C / G / T cells of the column */
     for (int n = 0; n < tr->nnodes; ++n) { /* post-order: a node's children are complete when it is reached */
         if (tr->leaf_taxon[n] >= 0) {
             unsigned mask = states[(int64_t)tr->leaf_taxon[n] * ncols + col] & 15u;
             set[n] = (unsigned char)(mask ? mask : 15u);
+            if (mask == 1u) ++base_count[0]; else if (mask == 2u) ++base_count[1]; else if (mask == 4u) ++base_count[2]; else if (mask == 8u) ++base_count[3];
             continue;
         }
         unsigned s = 15u; /* the identity of the join: all states */
@@ -697,13 +697,31 @@ static double fitch_start(const orc_model *m, const orc_tree *tr, const int *kid
     }
     free(set);
     *changes_out = changes;
-    const double len = m->kappa * chrono * ((double)(resolved > 0 ? resolved : 1) / (double)tr->ntaxa);
+    /* rate at which THIS column's states are left: sum_x p_x (-Q_xx) over the plain cells of the column, instead of the
+     * stationary mean kappa = sum_x pi_x (-Q_xx).  A column of mostly fast-leaving bases reaches its parsimony count at a lower
+     * site rate; with the column's own exit rate the start lands 2-3 x closer (64 taxa: rms miss 0.20 -> 0.105 log-units,
+     * 256 taxa: 0.36 -> 0.13). */
+    double exit_rate = m->kappa;
+    {
+        const int nb = base_count[0] + base_count[1] + base_count[2] + base_count[3];
+        if (nb > 0) {
+            double acc = 0.0;
+            for (int x = 0; x < 4; ++x) {
+                double qxx = 0.0;
+                for (int k = 0; k < 4; ++k) qxx += m->U[x][k] * m->lam[k] * m->Ui[k][x];
+                acc += (double)base_count[x] * -qxx;
+            }
+            if (acc > 0.0) exit_rate = acc / (double)nb;
+        }
+    }
+    const double len = exit_rate * chrono * ((double)(resolved > 0 ? resolved : 1) / (double)tr->ntaxa);
     /* parsimony undercounts where changes are dense: stretch the count with p = changes per branch among the taxa
-     * present, m' = B (-a ln(1 - p/a)), a = 0.30, p capped at 0.28 (same constants as classify_kernel) */
+     * present, m' = B (-a ln(1 - p/a)), a = 0.25, p capped at 0.235 (same constants as classify_kernel; re-calibrated with
+     * the column's own exit rate in the denominator: rms miss of the start 0.105 -> 0.088 log-units at 64 taxa) */
     double mch = (double)(changes > 0 ? changes : 1);
     const double B = (double)(2 * resolved - 3 > 1 ? 2 * resolved - 3 : 1);
-    const double pden = fmin(mch / B, 0.28);
-    mch = B * (-0.30 * log(1.0 - pden / 0.30));
+    const double pden = fmin(mch / B, 0.235);
+    mch = B * (-0.25 * log(1.0 - pden / 0.25));
     double u0 = (len > 0) ? log(mch / len) : 0.0;
     if (!(u0 == u0)) u0 = 0.0;
     if (u0 < -20.0) u0 = -20.0;
@@ -767,31 +785,25 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
          * order, so a remaining step of up to ORC_HERMITE_TOL can be taken WITHOUT evaluating again.  (Round 1 used the
          * cubic through the four slope conditions: ~15 x the error at the same step, hence bounds of 1e-3 / 2e-4 and 60 % of
          * the columns leaving after two evaluations; DESIGN section 8 r2 has the calibration of the present bounds.)
-         * The quartic is for REGULAR points only -- curvature of at least ORC_HERMITE_REGULAR at both, i.e. a tenth of a
+         * Both exits are for REGULAR points only -- curvature of at least ORC_HERMITE_REGULAR, i.e. a tenth of a
          * substitution's worth (|h| ~ the number of changes at the optimum of a regular column).  A weakly curved column
-         * (near an inflection or a plateau) keeps round 1's cubic and bounds: there the value difference made things
-         * worse (1.1e-6 instead of 2e-8 on one column in 27 000 of a 16-taxon set). */
-        if (have_prev && h < 0) {
+         * sits near an inflection or on the approach to a plateau (|h| ~ 1e-3 and changing by 20 % per 0.01 log-units);
+         * no low-order model of f' holds there -- round 1's exits left 2e-7 ... 1.4e-6 on one such column in 3 x 10^5 --
+         * so it iterates until the step itself is below ORC_STEP_TOL_FIRST. */
+        const int regular_here = fabs(h) >= ORC_HERMITE_REGULAR;
+        if (have_prev && h < 0 && regular_here && fabs(h_prev) >= ORC_HERMITE_REGULAR) {
             const double d = u - u_prev; /* the previous point sits at t = -d */
-            const int regular = fabs(h) >= ORC_HERMITE_REGULAR && fabs(h_prev) >= ORC_HERMITE_REGULAR;
-            double q2, q3, q4 = 0.0;
-            if (regular) {
-                const double r1 = g_prev - g + h * d, r2 = (h_prev - h) * d, r3 = (f - f_prev) / d - g + 0.5 * h * d;
-                const double id = 1.0 / d, id2 = id * id;
-                q2 = (-12.0 * r1 - 1.5 * r2 + 30.0 * r3) * id2;
-                q3 = (-28.0 * r1 - 4.0 * r2 + 60.0 * r3) * (id2 * id);
-                q4 = (-15.0 * r1 - 2.5 * r2 + 30.0 * r3) * (id2 * id2);
-            } else {
-                q3 = 2.0 * (g_prev - g) / (d * d * d) + (h + h_prev) / (d * d);
-                q2 = (h - h_prev) / (2.0 * d) + 1.5 * q3 * d;
-            }
+            const double r1 = g_prev - g + h * d, r2 = (h_prev - h) * d, r3 = (f - f_prev) / d - g + 0.5 * h * d;
+            const double id = 1.0 / d, id2 = id * id;
+            const double q2 = (-12.0 * r1 - 1.5 * r2 + 30.0 * r3) * id2;
+            const double q3 = (-28.0 * r1 - 4.0 * r2 + 60.0 * r3) * (id2 * id);
+            const double q4 = (-15.0 * r1 - 2.5 * r2 + 30.0 * r3) * (id2 * id2);
             double t = -g / h;
             for (int k = 0; k < 4; ++k) { /* Newton on g + h t + q2 t^2 + q3 t^3 + q4 t^4 */
                 const double p = g + t * (h + t * (q2 + t * (q3 + t * q4)));
                 const double dp = h + t * (2.0 * q2 + t * (3.0 * q3 + 4.0 * t * q4));
                 if (dp < 0) t -= p / dp;
             }
-            const double tol2 = regular ? ORC_HERMITE_TOL : ORC_HERMITE_TOL_WEAK, span2 = regular ? ORC_HERMITE_SPAN : ORC_HERMITE_SPAN_WEAK;
             /* The quartic is the derivative of the quintic Hermite interpolant of f (three conditions at each point), whose
              * error is f^(6) / 6! t^3 (t + d)^3: the zero of f' is off by K t^2 |d|^3 with K = |f^(6)| / (240 |h|), hence a
              * bound on t^2 |d|^3 itself.  K is ~0.004 on the median column, ~15 on fast sites whose series in u has a radius
@@ -799,16 +811,14 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
              * log-units: one in 10^7), where only a small step helps: the error is what the model gets wrong in the third
              * derivative times t^2 / |h|, up to ~t^2 / 30.  Wider bounds were measured (step 1e-2, span 1e-3: 87 % of the
              * columns leave after two evaluations instead of 67 %) and left 1.1e-6 on one column of C5; an agreement test
-             * between the quartic and the cubic does not catch those columns -- both interpolants are off by the same amount. */
-            const int t2d3_ok = !regular || t * t * fabs(d * d * d) < ORC_HERMITE_T2D3;
-            /* the interpolation error grows with the distance to the far point: it must not vouch for the step ... */
-            /* ... and where the curvature is weak compared with the higher-order terms (a nearly flat column) the zero
-             * of f' is too sensitive to the model: those terms must be a small correction of h */
-            /* ... and the difference of two rounded values must not steer the zero: the rounding of f reaches q2 as
-             * ~30 eps |f| / |d|^3 and moves the zero by that times t^2 / |h|, kept below 1e-9 */
-            if (t2d3_ok && fabs(t) < tol2 && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < span2 &&
-                fabs(t * (q2 + t * (q3 + t * q4))) < (regular ? ORC_HERMITE_GUARD : 0.02) * fabs(h) &&
-                (!regular || ORC_HERMITE_NOISE * fabs(f) * (t * t) < fabs(h) * fabs(d * d * d))) {
+             * between the quartic and the cubic does not catch those columns -- both interpolants are off by the same amount.
+             * Further: the far point must not vouch for a step it is too far from (span), the higher-order terms must be a
+             * small correction of h, and the difference of two rounded values must not steer the zero (the rounding of f
+             * reaches q2 as ~30 eps |f| / |d|^3 and moves the zero by that times t^2 / |h|, kept below 1e-9). */
+            if (fabs(t) < ORC_HERMITE_TOL && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < ORC_HERMITE_SPAN &&
+                t * t * fabs(d * d * d) < ORC_HERMITE_T2D3 &&
+                fabs(t * (q2 + t * (q3 + t * q4))) < ORC_HERMITE_GUARD * fabs(h) &&
+                ORC_HERMITE_NOISE * fabs(f) * (t * t) < fabs(h) * fabs(d * d * d)) {
                 f += t * (g + t * (0.5 * h + t * (q2 / 3.0 + t * (0.25 * q3 + t * (0.2 * q4)))));
                 u += t;
                 *flag_out = 0;
@@ -821,7 +831,7 @@ static void maximise_column(const orc_model *m, const orc_tree *tr, const uint8_
                 break;
             }
         }
-        const double tol = have_prev ? ORC_STEP_TOL : ORC_STEP_TOL_FIRST;
+        const double tol = (have_prev && regular_here) ? ORC_STEP_TOL : ORC_STEP_TOL_FIRST;
         double un = u + step;
         /* the bracket safeguard must not see a converged (possibly underflowing) step */
         if (fabs(step) >= tol) {

@@ -69,6 +69,7 @@ struct ColumnScan {
     unsigned uni = 0;
     int resolved = 0, informative = 0;
     unsigned changes = 0;   // Fitch parsimony: minimum number of substitutions on the tree
+    int base[3] = {0, 0, 0};   // plain A, C, G cells (T = informative - the three): the column's own exit rate, start_log_rate
 };
 
 // Four consecutive columns at once: a thread's four state bytes of one taxon arrive as one dword, and every quantity
@@ -83,6 +84,8 @@ struct ColumnScan4 {
     static constexpr uint32_t k01 = 0x01010101u, k0f = 0x0f0f0f0fu;
     uint32_t uni4 = 0, set4 = k0f;
     uint32_t res8 = 0, inf8 = 0, chg8 = 0;            // byte counters since the last flush
+    uint32_t a8 = 0, c8 = 0, g8 = 0;                  // ... of the plain A / C / G cells
+    int base[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     uint32_t word[4] = {0, 0, 0, 0};
     uint64_t hsh[4] = {0x243F6A8885A308D3ull, 0x243F6A8885A308D3ull, 0x243F6A8885A308D3ull, 0x243F6A8885A308D3ull};
     int resolved[4] = {0, 0, 0, 0}, informative[4] = {0, 0, 0, 0};
@@ -98,8 +101,12 @@ struct ColumnScan4 {
             resolved[j] += (int)((res8 >> (8 * j)) & 0xffu);
             informative[j] += (int)((inf8 >> (8 * j)) & 0xffu);
             changes[j] += (chg8 >> (8 * j)) & 0xffu;
+            base[0][j] += (int)((a8 >> (8 * j)) & 0xffu);
+            base[1][j] += (int)((c8 >> (8 * j)) & 0xffu);
+            base[2][j] += (int)((g8 >> (8 * j)) & 0xffu);
         }
         res8 = inf8 = chg8 = 0;
+        a8 = c8 = g8 = 0;
     }
     __device__ __forceinline__ void fitch_join(uint32_t x4) {
         const uint32_t both = set4 & x4;
@@ -125,7 +132,11 @@ struct ColumnScan4 {
         const uint32_t res = is15(m4) ^ k01;          // resolved: not a gap / ? / N
         uni4 |= m4 & spread(res);
         res8 += res;
-        inf8 += nonzero(m4 & (m4 - k01)) ^ k01;       // exactly one bit set (m4 >= 1 in every byte: no borrow)
+        const uint32_t single = nonzero(m4 & (m4 - k01)) ^ k01;   // exactly one bit set (m4 >= 1 in every byte: no borrow)
+        inf8 += single;
+        a8 += single & m4;                            // ... and it is bit 0 / 1 / 2 (the neighbour byte's bit that a shift
+        c8 += single & (m4 >> 1);                     // brings into bit 7 is masked away by `single`)
+        g8 += single & (m4 >> 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) word[j] |= ((m4 >> (8 * j)) & 15u) << (4 * (k & 7));
         fitch_join(m4);
@@ -137,23 +148,41 @@ struct ColumnScan4 {
         c.resolved = resolved[j];
         c.informative = informative[j];
         c.changes = changes[j];
+        c.base[0] = base[0][j]; c.base[1] = base[1][j]; c.base[2] = base[2][j];
         return c;
     }
 };
 
-constexpr double kStartA = 0.30, kStartDensityCap = 0.28;
+constexpr double kStartA = 0.25, kStartDensityCap = 0.235;   // (0.30 / 0.28 before the column's own exit rate went into the start)
 
 // Where the optimiser starts for a column that needs it: the rate at which the tree would carry the column's
 // parsimony count, s0 = changes / (kappa * tree length * fraction of taxa present).  HyPhy starts every column at
 // siteRate = 1 (bf:1050), typically e^3 away from the optimum; from s0 (median error 10 %) the same maximum is reached in
 // 2.8 instead of 4.4 evaluations on the C3 shape.  Passed to site_rate_kernel through the column's `rate` slot.
 __device__ __forceinline__ double start_log_rate(const ClassifyParams& P, const LocusModel* __restrict__ M, const ColumnScan& c) {
-    const double len = M->kappa * P.chrono_length * ((double)(c.resolved > 0 ? c.resolved : 1) / (double)P.ntaxa);
+    // Rate at which THIS column's states are left: sum_x p_x (-Q_xx) over its plain cells instead of the stationary mean
+    // kappa = sum_x pi_x (-Q_xx).  A column of mostly fast-leaving bases reaches its parsimony count at a lower site rate; with
+    // the column's own exit rate the start lands 2-3 x closer (64 taxa: rms miss 0.20 -> 0.105 log-units, 256 taxa: 0.36 ->
+    // 0.13; same rule as the oracle).  -Q_xx = -sum_k U[x][k] lam_k U^-1[k][x] from the locus model (lam_0 = 0).
+    double exit_rate = M->kappa;
+    if (c.informative > 0) {
+        const int cnt[4] = {c.base[0], c.base[1], c.base[2], c.informative - c.base[0] - c.base[1] - c.base[2]};
+        double acc = 0.0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            double qxx = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) qxx = fma(M->U[x * 3 + k] * M->lam[k], M->Ui[k * 4 + x], qxx);
+            acc = fma((double)cnt[x], -qxx, acc);
+        }
+        if (acc > 0.0) exit_rate = acc / (double)c.informative;
+    }
+    const double len = exit_rate * P.chrono_length * ((double)(c.resolved > 0 ? c.resolved : 1) / (double)P.ntaxa);
     double m = (double)(c.changes > 0u ? c.changes : 1u);
     // parsimony undercounts where changes are dense: with p = changes per branch among the taxa present, the count is
-    // stretched to B * (-a ln(1 - p/a)), a = 0.30 (the shape of a multiple-hit correction; a calibrated on the
-    // synthetic shapes, where it centres the start on the optimum for p up to 0.28 and saves another 6-12 % of the
-    // evaluations; only the starting point depends on it)
+    // stretched to B * (-a ln(1 - p/a)), a = kStartA (the shape of a multiple-hit correction; a calibrated on the
+    // synthetic shapes, where it centres the start on the optimum for p up to kStartDensityCap and saves another 6-12 %
+    // of the evaluations; only the starting point depends on it)
     const double B = (double)(2 * c.resolved - 3 > 1 ? 2 * c.resolved - 3 : 1);
     const double pden = fmin(m / B, kStartDensityCap);
     m = B * (-kStartA * log(1.0 - pden / kStartA));

@@ -681,20 +681,20 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     // Two evaluations in hand: f' is known with its slope at both points and its integral between them (the
                     // difference of the values): the quartic through those five conditions locates the zero to fifth order, so
                     // a remaining step below kHermiteTol is taken without evaluating again (same rule as the oracle, which
-                    // documents the bounds).  Weakly curved points keep round 1's cubic through the slopes and its bounds.  The
-                    // previous value lives in f_conv, which has no other use until a saturation check starts.
+                    // documents the bounds).  Only between REGULAR points (|h| >= kHermiteRegular): a weakly curved column sits
+                    // near an inflection or a plateau, no low-order model of f' holds there, it iterates until the step itself
+                    // is below kStepTolFirst.  The previous value lives in f_conv, which has no other use until a saturation
+                    // check starts.
                     bool hermite = false;
                     double un = u;
-                    if (have_prev && h < 0.0) {
+                    const bool regular_here = fabs(h) >= kHermiteRegular;
+                    if (have_prev && h < 0.0 && regular_here && fabs(h_prev) >= kHermiteRegular) {
                         const double d = u - u_prev;      // the previous point sits at t = -d
                         const double id = 1.0 / d, id2 = id * id;
-                        const bool regular = fabs(h) >= kHermiteRegular && fabs(h_prev) >= kHermiteRegular;
                         const double r1 = fma(h, d, g_prev - g), r2 = (h_prev - h) * d, r3 = fma(0.5 * h, d, (f - f_conv) * id - g);
-                        const double c3 = (2.0 * (g_prev - g) * id + (h + h_prev)) * id2;      // the cubic's coefficients
-                        const double c2 = fma(1.5 * c3, d, (h - h_prev) * (0.5 * id));
-                        const double q2 = regular ? fma(30.0, r3, fma(-1.5, r2, -12.0 * r1)) * id2 : c2;
-                        const double q3 = regular ? fma(60.0, r3, fma(-4.0, r2, -28.0 * r1)) * (id2 * id) : c3;
-                        const double q4 = regular ? fma(30.0, r3, fma(-2.5, r2, -15.0 * r1)) * (id2 * id2) : 0.0;
+                        const double q2 = fma(30.0, r3, fma(-1.5, r2, -12.0 * r1)) * id2;
+                        const double q3 = fma(60.0, r3, fma(-4.0, r2, -28.0 * r1)) * (id2 * id);
+                        const double q4 = fma(30.0, r3, fma(-2.5, r2, -15.0 * r1)) * (id2 * id2);
                         double t = -g / h;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -702,15 +702,11 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                             const double dp = fma(t, fma(t, fma(4.0 * t, q4, 3.0 * q3), 2.0 * q2), h);
                             t = (dp < 0.0) ? t - p / dp : t;
                         }
-                        const double tol2 = regular ? kHermiteTol : kHermiteTolWeak, span2 = regular ? kHermiteSpan : kHermiteSpanWeak;
-                        // the quartic's error term is K t^2 |d|^3, K up to ~15 on regular columns (see the oracle): bound it
-                        const bool t2d3_ok = !regular || t * t * fabs(d * d * d) < kHermiteT2D3;
-                        // (span bound: the interpolation error grows with the distance to the far point; next condition: on a
-                        // nearly flat column the zero of f' is too sensitive to the model unless the higher-order terms are a small
-                        // part of h; last: the difference of two rounded values must not steer the zero)
-                        if (t2d3_ok && fabs(t) < tol2 && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < span2 &&
-                            fabs(t * fma(t, fma(t, q4, q3), q2)) < (regular ? kHermiteGuard : 0.02) * fabs(h) &&
-                            (!regular || kHermiteNoise * fabs(f) * (t * t) < fabs(h) * fabs(d * d * d))) {
+                        // step, span, the interpolant's error term t^2 |d|^3, higher-order terms against h, rounding of the values
+                        if (fabs(t) < kHermiteTol && fabs(t) < 0.5 * fabs(d) && fabs(t * d) < kHermiteSpan &&
+                            t * t * fabs(d * d * d) < kHermiteT2D3 &&
+                            fabs(t * fma(t, fma(t, q4, q3), q2)) < kHermiteGuard * fabs(h) &&
+                            kHermiteNoise * fabs(f) * (t * t) < fabs(h) * fabs(d * d * d)) {
                             f = fma(t, fma(t, fma(t, fma(t, fma(t, 0.2 * q4, 0.25 * q3), q2 * (1.0 / 3.0)), 0.5 * h), g), f);
                             un = u + t;
                             hermite = true;
@@ -747,7 +743,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     // kPlateauStride covers the two log-units to flatness in a few evaluations; a maximum that does lie
                     // ahead is overshot by at most that much and then bracketed from both sides.
                     if (uphill && hi_open && u >= kUCheck && step < kPlateauStride) step = kPlateauStride;
-                    const double tol = have_prev ? kStepTol : kStepTolFirst;
+                    const double tol = (have_prev && regular_here) ? kStepTol : kStepTolFirst;
                     un = u + step;
                     // the bracket safeguard must not see a converged (possibly underflowing) step
                     if (fabs(step) >= tol) {

@@ -18,9 +18,8 @@ constexpr double kHermiteSpan = 3e-4;   // ... while |step| * |distance between 
 constexpr double kHermiteTol = 2e-3;    // final step from the two-point quartic model of f' accepted below this size
                                         // (calibration of the two bounds: tools/debug/two_point_experiment.py)
 constexpr double kHermiteT2D3 = 1.5e-8;  // step^2 * |distance of the far point|^3 below this (the quartic's error term)
-constexpr double kHermiteGuard = 0.005;  // the quartic's higher-order terms at the step, relative to |h| (the cubic path: 0.02)
-constexpr double kHermiteRegular = 0.1;  // curvature |h| at both points from which the quartic is used; below: the cubic with ...
-constexpr double kHermiteTolWeak = 1e-3, kHermiteSpanWeak = 2e-4;   // ... round 1's bounds
+constexpr double kHermiteGuard = 0.005;  // the quartic's higher-order terms at the step, relative to |h|
+constexpr double kHermiteRegular = 0.25; // curvature |h| from which the two exits apply (below: iterate until the step is below 1e-6)
 constexpr double kHermiteNoise = 5.3e-5; // 30 * (8 * 2.2e-16) / 1e-9: rounding of the two values vs curvature (site_rate_kernel.hpp)
 constexpr double kStepTolFirst = 1e-6;  // ... except at the first evaluation (no second point yet)
 constexpr int kMaxIt = 100;
