@@ -576,6 +576,33 @@ def test_site_rate_kernel_variants(oracle, monkeypatch, persistent, byte_path):
         plan.close()
 
 
+@pytest.mark.parametrize("ntaxa,ncols,kw", [(9, 30000, dict(rate_mean=0.05, gap_frac=0.3)), (64, 20000, dict(rate_mean=0.3)),
+                                            (16, 30000, {}), (5, 30000, dict(rate_mean=0.02, gap_frac=0.15))])
+def test_optimiser_exits_leave_no_residual_on_hard_shapes(ntaxa, ncols, kw):
+    """The two exits that save the confirming evaluation (two-point quartic, third-order corrected Newton step) are sized by the
+    residual tails of the BASELINE configs (tests/test_gpu_fullsize.py); this is the same bound, |f'/f''| < 1e-6 at every
+    reported interior maximiser, on the shapes where low-order models of f' are least at home: few taxa with many gaps (nearly
+    flat columns), fast sites near saturation, 16 taxa, 5 noisy taxa."""
+    engine = _engine()
+    from tapir_amd import synth
+    d = synth.simulate(1, ncols, ntaxa, 20261007 + ntaxa, **kw)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], pin["T"], [10], [[5, 15]],
+                       correction=pin["correction"])
+    got = plan.site_rates(st)
+    ok = got["flag"] == 0
+    kappa = plan.models()[3][0]
+    u = np.zeros(ncols)
+    u[ok] = np.log(got["rate"][ok] / kappa)
+    f, g, h = plan.eval_columns(st, u)
+    plan.close()
+    assert ok.sum() > ncols // 4 and np.all(h[ok] < 0)
+    resid = np.abs(g[ok] / h[ok])
+    assert resid.max() < 1e-6, (resid.max(), np.abs(h[ok])[np.argmax(resid)])
+    assert np.abs(f[ok] - got["lnl"][ok]).max() < 1e-9 * np.abs(got["lnl"][ok]).max()
+
+
 def test_fused_cherries_follow_the_branch_lengths(oracle):
     """The packed path folds TIP_SET + TIP_MUL on EQUALLY long branches into one CHERRY op (shared exponentials).
     A chronogram's cherries all qualify; lengthening one tip of a cherry must take exactly that pair out of the
