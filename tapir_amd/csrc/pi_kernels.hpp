@@ -159,22 +159,30 @@ constexpr double kStartA = 0.25, kStartDensityCap = 0.235;   // (0.30 / 0.28 bef
 // parsimony count, s0 = changes / (kappa * tree length * fraction of taxa present).  HyPhy starts every column at
 // siteRate = 1 (bf:1050), typically e^3 away from the optimum; from s0 (median error 10 %) the same maximum is reached in
 // 2.8 instead of 4.4 evaluations on the C3 shape.  Passed to site_rate_kernel through the column's `rate` slot.
-__device__ __forceinline__ double start_log_rate(const ClassifyParams& P, const LocusModel* __restrict__ M, const ColumnScan& c) {
+// -Q_xx of the locus' model for x = A, C, G, T: -sum_k U[x][k] lam_k U^-1[k][x] (lam_0 = 0); once per thread, the four columns
+// of a thread belong to one locus
+__device__ __forceinline__ void exit_rates(const LocusModel* __restrict__ M, double* ex) {
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        double qxx = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) qxx = fma(M->U[x * 3 + k] * M->lam[k], M->Ui[k * 4 + x], qxx);
+        ex[x] = -qxx;
+    }
+}
+
+__device__ __forceinline__ double start_log_rate(const ClassifyParams& P, const LocusModel* __restrict__ M, const ColumnScan& c,
+                                                 const double* ex) {
     // Rate at which THIS column's states are left: sum_x p_x (-Q_xx) over its plain cells instead of the stationary mean
     // kappa = sum_x pi_x (-Q_xx).  A column of mostly fast-leaving bases reaches its parsimony count at a lower site rate; with
     // the column's own exit rate the start lands 2-3 x closer (64 taxa: rms miss 0.20 -> 0.105 log-units, 256 taxa: 0.36 ->
-    // 0.13; same rule as the oracle).  -Q_xx = -sum_k U[x][k] lam_k U^-1[k][x] from the locus model (lam_0 = 0).
+    // 0.13; same rule as the oracle).  ex[x] = -Q_xx (exit_rates).
     double exit_rate = M->kappa;
     if (c.informative > 0) {
         const int cnt[4] = {c.base[0], c.base[1], c.base[2], c.informative - c.base[0] - c.base[1] - c.base[2]};
         double acc = 0.0;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            double qxx = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) qxx = fma(M->U[x * 3 + k] * M->lam[k], M->Ui[k * 4 + x], qxx);
-            acc = fma((double)cnt[x], -qxx, acc);
-        }
+        for (int x = 0; x < 4; ++x) acc = fma((double)cnt[x], ex[x], acc);
         if (acc > 0.0) exit_rate = acc / (double)c.informative;
     }
     const double len = exit_rate * P.chrono_length * ((double)(c.resolved > 0 ? c.resolved : 1) / (double)P.ntaxa);
@@ -192,7 +200,7 @@ __device__ __forceinline__ double start_log_rate(const ClassifyParams& P, const 
 }
 
 __device__ __forceinline__ void classify_finish(const ClassifyParams& P, const LocusModel* __restrict__ M, int64_t col,
-                                                const ColumnScan& c, uint8_t& flg_out) {
+                                                const ColumnScan& c, const double* ex, uint8_t& flg_out) {
     uint8_t flg = TPHIP_FLAG_OK;  // provisional: site_rate_kernel will overwrite
     if (c.resolved <= 1) flg = TPHIP_FLAG_FLAT;
     else if (__popc(c.uni) == 1) flg = TPHIP_FLAG_ZERO;
@@ -213,7 +221,7 @@ __device__ __forceinline__ void classify_finish(const ClassifyParams& P, const L
     } else {
         // u0 for site_rate_kernel, which overwrites it with the answer: the parsimony start, or u = log 1 = 0 when the
         // plan asks for HyPhy's start value (start_scale = 0; a multiplication, not a branch: + 0.0 turns -0.0 into 0.0)
-        P.rate[col] = start_log_rate(P, M, c) * P.start_scale + 0.0;
+        P.rate[col] = start_log_rate(P, M, c, ex) * P.start_scale + 0.0;
         // the column's parsimony length for the optimiser's first step (site_rate_kernel overwrites the slot with the answer);
         // 0 = none: HyPhy's start value asks for the plain step from there, and on small trees an evaluation is so cheap that
         // the extra logarithm costs more than the saved evaluations (C2, 16 taxa: +4 % time with it; C3 -2 %, C5 -4 %)
@@ -292,8 +300,10 @@ __global__ __launch_bounds__(kPiBlock) void classify_kernel(ClassifyParams P) {
     }
     c.flush();
     uint8_t f[4] = {0, 0, 0, 0};
+    double ex[4];
+    exit_rates(M, ex);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (j < n) classify_finish(P, M, c0 + j, c.column(j), f[j]);
+    for (int j = 0; j < 4; ++j) if (j < n) classify_finish(P, M, c0 + j, c.column(j), ex, f[j]);
     if (P.hash) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < n) P.hash[c0 + j] = c.hsh[j] ^ (c.hsh[j] >> 32);
