@@ -23,6 +23,38 @@ def _read_one(path):
     return nexus.read_states(path)
 
 
+def _peek_nchar(path):
+    """NCHAR of a NEXUS file from its first block (None when the header does not say)."""
+    import re
+    with open(path) as fh:
+        head = fh.read(4096)
+    m = re.search(r"dimensions\s+[^;]*?nchar\s*=\s*(\d+)", head, flags=re.I)
+    return int(m.group(1)) if m else None
+
+
+_PARSE_VIEWS = {}
+
+
+def _parse_into(job):
+    """Pool worker: parse one alignment and put its rows, in the tree's leaf order, at its columns of the batch array the
+    parent created in /dev/shm.  Returns None, or what went wrong (the parent raises)."""
+    shared, ntaxa, total, path, c0, n, leaf_names = job
+    arr = _PARSE_VIEWS.get(shared)
+    if arr is None:
+        _PARSE_VIEWS.clear()
+        arr = _PARSE_VIEWS[shared] = np.memmap(shared, dtype=np.uint8, mode="r+", shape=(ntaxa, total))
+    try:
+        names, st = nexus.read_states(path)
+    except Exception as e:   # reported by the parent with the file's name
+        return ("error", "%s: %s" % (os.path.basename(path), e))
+    if set(names) != set(leaf_names):
+        return ("taxa", names)
+    if st.shape[1] != n:
+        return ("nchar", st.shape[1])
+    arr[:, c0:c0 + n] = st[[names.index(x) for x in leaf_names]]
+    return None
+
+
 class HostPool:
     """Worker processes for the host-side text work of a run (NEXUS parsing, `.rates` JSON formatting) -- the part of
     `Pool(cpu_count() - 1).map(worker, params)` (bin/tapir_compute.py:159-164) that is still CPU work here.
@@ -39,6 +71,40 @@ class HostPool:
 
     def parse(self, paths):
         return self._pool.map(_read_one, paths, chunksize=max(1, len(paths) // (8 * self.workers)))
+
+    def parse_into(self, paths, leaf_names, alloc):
+        """The batch array [ntaxa, total columns] filled by the workers themselves through a file in /dev/shm: returning
+        50 000 parsed matrices through the pool's pipes (3.2 GB pickled) cost more than parsing them.  Returns
+        (states, offsets), or None when this route does not apply (no /dev/shm, a header without NCHAR or one that
+        disagrees with its matrix: the caller then takes the plain route, which also words the error messages)."""
+        shm = _shared_dir()
+        if shm is None:
+            return None
+        chunk = max(1, len(paths) // (8 * self.workers))
+        nchar = self._pool.map(_peek_nchar, paths, chunksize=chunk)
+        if any(n is None or n <= 0 for n in nchar):
+            return None
+        offsets = np.concatenate([[0], np.cumsum(nchar)]).astype(np.int64)
+        ntaxa, total = len(leaf_names), int(offsets[-1])
+        import tempfile
+        fd, shared = tempfile.mkstemp(prefix="tapir_amd_states_", dir=shm)
+        os.close(fd)
+        try:
+            mm = np.memmap(shared, dtype=np.uint8, mode="w+", shape=(ntaxa, total))
+            names = tuple(leaf_names)
+            jobs = [(shared, ntaxa, total, p, int(offsets[i]), int(nchar[i]), names) for i, p in enumerate(paths)]
+            res = self._pool.map(_parse_into, jobs, chunksize=chunk)
+            if any(r is not None for r in res):
+                return None
+            states = alloc((ntaxa, total), np.uint8)
+            states[...] = mm
+            del mm
+        finally:
+            try:
+                os.unlink(shared)
+            except OSError:
+                pass
+        return states, offsets
 
     def write_rates(self, jobs, progress=None):
         for _ in self._pool.imap_unordered(_write_job, jobs, chunksize=max(1, len(jobs) // (8 * self.workers))):
@@ -64,6 +130,9 @@ def load_alignments(paths, leaf_names, pool=None, alloc=None):
     requires of (siteFilter, siteTree).  pool: a HostPool parses the files in parallel (--multiprocessing).
     alloc(shape, dtype): where the flattened array lives (engine.pinned_empty: the H2D copy is then direct DMA)."""
     if pool is not None and len(paths) > 1:
+        direct = pool.parse_into(paths, leaf_names, alloc or np.empty) if hasattr(pool, "parse_into") else None
+        if direct is not None:
+            return direct
         parsed = pool.parse(paths)
     else:
         parsed = [_read_one(p) for p in paths]
@@ -97,22 +166,41 @@ def format_rates_json(freqs, exch, site, subst, rate, ll, corrected):
     }}
 
 
+def _repr_rounded(arr, decimals=4):
+    """[repr(float("%.4f" % v)) for v in arr] without a Python-level step per element: the rounding is compute.round_like_hyphy
+    (the double nearest to the printf-rounded decimal, vectorised), repr runs over a plain list inside map().  Values too large
+    for the vectorised rounding to be exact (|v| * 10^decimals beyond 2^52) and non-finite ones take the literal route."""
+    from .compute import round_like_hyphy
+    a = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1)
+    out = list(map(repr, round_like_hyphy(a, decimals).tolist()))
+    odd = np.flatnonzero(~(np.abs(a) < 2.0 ** 52 / 10.0 ** decimals))
+    for k in odd.tolist():
+        out[k] = repr(float("%.*f" % (decimals, a[k])))
+    return out
+
+
+_ROW = ('            {\n                "site": ', ',\n                "subst": ', ',\n                "rate": ',
+        ',\n                "ll": ', '\n            },\n')
+_CROW = ('            {\n                "site": ', ',\n                "rate": ', '\n            },\n')
+
+
 def dumps_rates_json(freqs, exch, site, subst, rate, ll, corrected):
-    """The text `json.dumps(format_rates_json(...), indent=4)` would produce, built by bulk string formatting:
-    the generic encoder spends ~30 us per site (it dominated the whole CLI), this ~1 us."""
-    f4 = lambda arr: [repr(float("%.4f" % v)) for v in arr]  # noqa: E731  (json writes floats with float.__repr__)
-    sub, rat, lls = f4(subst), f4(rate), f4(ll)
-    cor = [repr(float(v)) for v in corrected]
-    sites = [int(x) for x in site]
+    """The text `json.dumps(format_rates_json(...), indent=4)` would produce, built by bulk string operations: the generic
+    encoder spends ~30 us per site (it dominated the whole CLI), a formatted row per site ~2 us, this ~0.6 us (every
+    per-site step -- rounding, repr, interleaving the fixed text -- runs inside numpy, map() or str.join)."""
+    from itertools import chain, repeat
+    sub, rat, lls = _repr_rounded(subst), _repr_rounded(rate), _repr_rounded(ll)
+    cor = list(map(repr, np.ascontiguousarray(corrected, dtype=np.float64).reshape(-1).tolist()))   # json writes float.__repr__
+    sites = list(map(str, np.asarray(site).astype(np.int64).reshape(-1).tolist()))
     head = ('{\n    "sites": {\n        "freqs": {\n            "A": %s,\n            "C": %s,\n            "G": %s,\n'
             '            "T": %s\n        },\n        "subs_matrix": {\n            "AC": %s,\n            "AG": %s,\n'
             '            "AT": %s,\n            "CG": %s,\n            "CT": %s,\n            "GT": %s\n        },\n'
             % tuple(repr(float(x)) for x in list(freqs) + list(exch)))
     if sites:
-        rows = ",\n".join('            {\n                "site": %d,\n                "subst": %s,\n                "rate": %s,\n'
-                          '                "ll": %s\n            }' % t for t in zip(sites, sub, rat, lls))
-        crow = ",\n".join('            {\n                "site": %d,\n                "rate": %s\n            }' % t
-                          for t in zip(sites, cor))
+        a, b, c, d, e = _ROW
+        rows = "".join(chain.from_iterable(zip(repeat(a), sites, repeat(b), sub, repeat(c), rat, repeat(d), lls, repeat(e))))[:-2]
+        a, b, e = _CROW
+        crow = "".join(chain.from_iterable(zip(repeat(a), sites, repeat(b), cor, repeat(e))))[:-2]
         body = '        "rates": [\n%s\n        ],\n        "corrected_rates": [\n%s\n        ]\n' % (rows, crow)
     else:
         body = '        "rates": [],\n        "corrected_rates": []\n'

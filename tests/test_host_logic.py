@@ -437,6 +437,41 @@ def test_fast_rates_writer_is_byte_identical_to_json_dump():
         assert json.loads(a)["sites"]["freqs"]["A"] == float(pi[0])
 
 
+def test_pool_parses_alignments_straight_into_the_batch_array(tmp_path):
+    """--multiprocessing: the workers write their parsed rows into the batch array through /dev/shm (HostPool.parse_into)
+    instead of returning them through the pool's pipes; same array and offsets as the sequential reader, ragged loci and a
+    permuted taxon order included, and files the direct route cannot size (no NCHAR in the header) fall back silently."""
+    from tapir_amd import pipeline, synth
+    d = synth.simulate(7, 60, 6, 5)
+    st = d["states"].numpy()
+    off = d["locus_offsets"].copy()
+    off[3] -= 11                                  # ragged: locus 2 is shorter, locus 3 longer
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    synth.write_nexus_dir(str(aln), st, off, d["names"], d["root"])
+    paths = sorted(str(aln / f) for f in os.listdir(aln) if f.endswith(".nex"))
+    # one file lists its taxa in another order
+    text = open(paths[1]).read().split("matrix\n")
+    rows = text[1].split("\n")
+    body, tail = rows[:6], rows[6:]
+    open(paths[1], "w").write(text[0] + "matrix\n" + "\n".join(body[::-1] + tail))
+    leaf = list(d["names"])
+    ref_states, ref_off = pipeline.load_alignments(paths, leaf)
+    with pipeline.HostPool(2) as pool:
+        got_states, got_off = pipeline.load_alignments(paths, leaf, pool=pool)
+        assert np.array_equal(got_states, ref_states) and np.array_equal(got_off, ref_off)
+        # a header without NCHAR: the direct route declines, the plain one still reads the file
+        t = open(paths[2]).read()
+        import re
+        open(paths[2], "w").write(re.sub(r"nchar=\d+", "", t))
+        assert pool.parse_into(paths, leaf, np.empty) is None
+        got_states, got_off = pipeline.load_alignments(paths, leaf, pool=pool)
+        assert np.array_equal(got_states, ref_states) and np.array_equal(got_off, ref_off)
+        # taxa that do not match the tree: the plain route words the error
+        with pytest.raises(pipeline.PipelineError, match="do not match the tree"):
+            pipeline.load_alignments(paths, leaf[:-1] + ["nobody"], pool=pool)
+
+
 def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, oracle):
     """--multiprocessing (reference: Pool(cpu_count()-1), bin/tapir_compute.py:159-164) parallelises only the
     host side; every output file must be identical to the sequential run."""
