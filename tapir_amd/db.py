@@ -56,14 +56,27 @@ def insert_pi_data(conn, c, pis):
 
 
 def insert_tables(conn, c, names, tables, T, times, intervals):
-    """Bulk form for the batch engine: tables[l] = [net(T) | disc(n_t) | integral(n_i) | error(n_i)]."""
+    """Bulk form for the batch engine: tables[l] = [net(T) | disc(n_t) | integral(n_i) | error(n_i)].  One executemany per
+    table over columns prepared with numpy (C4: 5.4 M rows; a list comprehension per locus was half of the stage's time).
+    Row order inside each table is locus by locus, as the reference's loop writes them (tapir/db.py:44-61)."""
+    import numpy as np
+    L = len(names)
+    if L == 0:
+        return
     n_t, n_i = len(times), len(intervals)
     labels = ["{0}-{1}".format(a, b) for a, b in intervals]
-    for l, name in enumerate(names):
-        row = tables[l]
-        c.execute("INSERT INTO loci(locus) VALUES (?)", (locus_name(name),))
-        key = c.lastrowid
-        c.executemany("INSERT INTO net VALUES (?,?,?)", [(key, k, float(row[k])) for k in range(T)])
-        c.executemany("INSERT INTO discrete VALUES (?,?,?)", [(key, int(times[k]), float(row[T + k])) for k in range(n_t)])
+    tables = np.asarray(tables, dtype=np.float64)
+    c.executemany("INSERT INTO loci(locus) VALUES (?)", [(locus_name(n),) for n in names])
+    keys = [r[0] for r in c.execute("SELECT id FROM loci ORDER BY id DESC LIMIT ?", (L,)).fetchall()][::-1]
+    keys = np.asarray(keys, dtype=np.int64)
+    if T:
+        c.executemany("INSERT INTO net VALUES (?,?,?)",
+                      zip(np.repeat(keys, T).tolist(), np.tile(np.arange(T), L).tolist(), tables[:, :T].reshape(-1).tolist()))
+    if n_t:
+        c.executemany("INSERT INTO discrete VALUES (?,?,?)",
+                      zip(np.repeat(keys, n_t).tolist(), np.tile(np.asarray(times, dtype=np.int64), L).tolist(),
+                          tables[:, T:T + n_t].reshape(-1).tolist()))
+    if n_i:
         c.executemany("INSERT INTO interval VALUES (?,?,?,?)",
-                      [(key, labels[k], float(row[T + n_t + k]), float(row[T + n_t + n_i + k])) for k in range(n_i)])
+                      zip(np.repeat(keys, n_i).tolist(), labels * L, tables[:, T + n_t:T + n_t + n_i].reshape(-1).tolist(),
+                          tables[:, T + n_t + n_i:T + n_t + 2 * n_i].reshape(-1).tolist()))
