@@ -77,8 +77,7 @@ class HostPool:
         50 000 parsed matrices through the pool's pipes (3.2 GB pickled) cost more than parsing them.  Returns
         (states, offsets), or None when this route does not apply (no /dev/shm, a header without NCHAR or one that
         disagrees with its matrix: the caller then takes the plain route, which also words the error messages)."""
-        shm = _shared_dir()
-        if shm is None:
+        if _shared_dir() is None:
             return None
         chunk = max(1, len(paths) // (8 * self.workers))
         nchar = self._pool.map(_peek_nchar, paths, chunksize=chunk)
@@ -86,6 +85,9 @@ class HostPool:
             return None
         offsets = np.concatenate([[0], np.cumsum(nchar)]).astype(np.int64)
         ntaxa, total = len(leaf_names), int(offsets[-1])
+        shm = _shared_dir(ntaxa * total)
+        if shm is None:
+            return None
         import tempfile
         fd, shared = tempfile.mkstemp(prefix="tapir_amd_states_", dir=shm)
         os.close(fd)
@@ -227,8 +229,20 @@ def _write_job(job):
     return path
 
 
-def _shared_dir():
-    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+def _shared_dir(need_bytes=0):
+    """/dev/shm when it is there, writable and has room for `need_bytes` (a tmpfs that fills up under a memory map kills
+    the writer with SIGBUS: containers often give it 64 MB), else None."""
+    d = "/dev/shm"
+    if not (os.path.isdir(d) and os.access(d, os.W_OK)):
+        return None
+    if need_bytes:
+        import shutil
+        try:
+            if shutil.disk_usage(d).free < 1.2 * need_bytes + (64 << 20):
+                return None
+        except OSError:
+            return None
+    return d
 
 
 STAGE1_BLOCK_LOCI = 8192   # loci fitted together (bounds memory: 8192 x 202 models x 9-point stencils = 15 M candidates at most).
@@ -335,10 +349,10 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
         if pool is not None and L > 1:
             import tempfile
             # the workers were forked before these arrays existed: hand them over through one shared file
-            fd, shared = tempfile.mkstemp(prefix="tapir_amd_", suffix=".f64", dir=_shared_dir())
+            total = int(offsets[-1])
+            fd, shared = tempfile.mkstemp(prefix="tapir_amd_", suffix=".f64", dir=_shared_dir(32 * max(total, 1)))
             os.close(fd)
             try:
-                total = int(offsets[-1])
                 arr = np.memmap(shared, dtype=np.float64, mode="w+", shape=(4, max(total, 1)))
                 arr[0, :total], arr[1, :total], arr[2, :total], arr[3, :total] = out["subst"], rate4, out["lnl"], corrected
                 arr.flush()
