@@ -435,6 +435,13 @@ def test_fast_rates_writer_is_byte_identical_to_json_dump():
         a = json.dumps(pipeline.format_rates_json(pi, ex, site, subst, rate, ll, rate / 100), indent=4)
         assert pipeline.dumps_rates_json(pi, ex, site, subst, rate, ll, rate / 100) == a
         assert json.loads(a)["sites"]["freqs"]["A"] == float(pi[0])
+    # values where a vectorised rounding could differ from "%.4f": signed zeros, decimal ties whose binary neighbour decides,
+    # magnitudes beyond 2^52 / 10^4 (taken literally), denormals
+    v = np.array([0.0, -0.0, 1e-5, -1e-5, 0.00005, 0.00015, 0.12345, 2.5e-5, 1234.56785, 1e15, 1e22, 123456789.123456, 5e-324,
+                  0.99995, 2.00005, 1.00015])
+    site = np.arange(1, len(v) + 1)
+    a = json.dumps(pipeline.format_rates_json(pi, ex, site, v, v, -v, v / 100), indent=4)
+    assert pipeline.dumps_rates_json(pi, ex, site, v, v, -v, v / 100) == a
 
 
 def test_pool_parses_alignments_straight_into_the_batch_array(tmp_path):
