@@ -248,6 +248,8 @@ static int make_parts(tphip_plan* p) {
         cut.push_back(l);
     }
     cut.push_back(L);
+    for (size_t k = 0; k + 1 < cut.size(); ++k)
+        if (S.offsets[cut[k + 1]] == S.offsets[cut[k]]) { p->host_split = 1; return TPHIP_OK; }   // a group without columns: no pipeline
     for (size_t k = 0; k + 1 < cut.size(); ++k) {
         const int64_t l0 = cut[k], l1 = cut[k + 1];
         std::vector<int64_t> off(S.offsets.begin() + l0, S.offsets.begin() + l1 + 1);
@@ -261,7 +263,12 @@ static int make_parts(tphip_plan* p) {
         d.cat_weight = S.cat_weight.empty() ? nullptr : S.cat_weight.data();
         tphip_plan* q = nullptr;
         const int rc = tphip_plan_create(&d, &q);
-        if (rc) { for (tphip_plan* r : p->parts) (void)tphip_plan_destroy(r); p->parts.clear(); return rc; }
+        if (rc) {   // whatever stops a group's plan: run the batch whole (the plain path reports real errors itself)
+            for (tphip_plan* r : p->parts) (void)tphip_plan_destroy(r);
+            p->parts.clear();
+            p->host_split = 1;
+            return TPHIP_OK;
+        }
         q->is_part = true;
         p->parts.push_back(q);
     }
@@ -1243,6 +1250,10 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
     }
     int rc = make_parts(p);
     if (rc) return rc;
+    if (p->parts.empty()) {   // the batch does not cut into groups with columns
+        rc = host_enqueue(p, states, (size_t)p->ncols, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables, do_site, do_pi);
+        return rc ? rc : host_wait(p);
+    }
     const size_t W = (size_t)tphip_plan_table_width(p);
     p->last_run_in_parts = true;
     hipEvent_t after = nullptr;

@@ -848,6 +848,15 @@ def test_host_pointer_pipeline_of_locus_groups_is_bit_identical(monkeypatch):
     for k in ("3", "4", "9", "pageable"):
         for key in outs["1"]:
             assert np.array_equal(outs["1"][key], outs[k][key], equal_nan=True), (k, key)
+    # a batch that does not cut into groups with columns (one locus holds everything, the others are empty): run whole
+    off1 = np.array([0, st.shape[1], st.shape[1], st.shape[1], st.shape[1]])
+    pi1, ex1 = np.repeat(d["pi"][:1], 4, axis=0), np.repeat(d["exch"][:1], 4, axis=0)
+    plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off1, pi1, ex1, pin["T"], [3, 9], [[1, 8], [2, 20]],
+                       correction=pin["correction"])
+    a, b = plan.run_fused(stp, pinned=True), plan.run_fused(st)
+    plan.close()
+    for key in a:
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
 
 
 def _balanced_tree(levels, rng):
