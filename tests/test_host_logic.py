@@ -479,6 +479,29 @@ def test_pool_parses_alignments_straight_into_the_batch_array(tmp_path):
             pipeline.load_alignments(paths, leaf[:-1] + ["nobody"], pool=pool)
 
 
+def test_shared_memory_files_need_room(tmp_path, monkeypatch):
+    """A tmpfs that fills up under a memory map kills the process with SIGBUS (containers often give /dev/shm 64 MB), so
+    /dev/shm is used only when it has room: the direct parsing route declines, the writers' hand-over file goes to the
+    ordinary temp directory."""
+    import collections
+    import shutil
+    from tapir_amd import pipeline, synth
+    usage = collections.namedtuple("usage", "total used free")
+    monkeypatch.setattr(shutil, "disk_usage", lambda d: usage(1 << 26, (1 << 26) - 4096, 4096))
+    assert pipeline._shared_dir(1 << 20) is None
+    if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK):
+        assert pipeline._shared_dir() == "/dev/shm"          # no size asked: only presence
+    d = synth.simulate(3, 40, 5, 9)
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    synth.write_nexus_dir(str(aln), d["states"].numpy(), d["locus_offsets"], d["names"], d["root"])
+    paths = sorted(str(aln / f) for f in os.listdir(aln) if f.endswith(".nex"))
+    with pipeline.HostPool(2) as pool:
+        assert pool.parse_into(paths, list(d["names"]), np.empty) is None
+        states, off = pipeline.load_alignments(paths, list(d["names"]), pool=pool)     # the plain route still works
+    assert np.array_equal(states, d["states"].numpy()) and np.array_equal(off, d["locus_offsets"])
+
+
 def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, oracle):
     """--multiprocessing (reference: Pool(cpu_count()-1), bin/tapir_compute.py:159-164) parallelises only the
     host side; every output file must be identical to the sequential run."""
