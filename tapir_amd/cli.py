@@ -197,6 +197,19 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
     cat_rates, cat_weights = (compute.discrete_gamma(args.gamma_alpha, args.gamma_categories)
                               if args.gamma_categories > 1 else (None, None))
     W = T + len(args.times) + 2 * len(args.intervals)
+    db_name = os.path.join(args.output, 'phylogenetic-informativeness.sqlite')
+    stored = False
+
+    def store(pis):   # tapir_compute.py's last step; single process: may run while the pool writes the .rates files
+        import time
+        t_db = time.perf_counter()
+        conn, c = db.create_probe_db(db_name)
+        db.insert_pi_data(conn, c, pis)
+        conn.commit()
+        c.close()
+        conn.close()
+        LAST_TIMINGS["sqlite"] = time.perf_counter() - t_db
+
     if not args.site_rates:
         if rank == 0:
             print("\nEstimating site rates and PI for files:")
@@ -214,10 +227,15 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
                                                round_decimals=-1 if args.full_precision_rates else 4,
                                                engine_mod=engine_mod, progress=progress, pool=pool,
                                                cat_rates=cat_rates, cat_weights=cat_weights,
-                                               start_rule=1 if args.reference_start else 0)
+                                               start_rule=1 if args.reference_start else 0,
+                                               during_write=store if world == 1 else None)
             tables = out["final_tables"]
+            stored = bool(out.get("during_write_done"))
+            sqlite_seconds = LAST_TIMINGS.get("sqlite")
             LAST_TIMINGS.clear()
             LAST_TIMINGS.update(out.get("timings", {}))
+            if stored:
+                LAST_TIMINGS["sqlite"] = sqlite_seconds
         else:
             pis, tables = [], np.zeros((0, W))
     else:
@@ -235,23 +253,23 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
     all_tables = _gather_rows(tables, len(files), rank, world, on_gpu)
     if rank == 0:
         # store results somewhere
-        import time
-        t_db = time.perf_counter()
-        db_name = os.path.join(args.output, 'phylogenetic-informativeness.sqlite')
         sys.stdout.write("\nStoring results in {0}...".format(db_name))
         sys.stdout.flush()
-        conn, c = db.create_probe_db(db_name)
         if world == 1:
-            db.insert_pi_data(conn, c, pis)
+            if not stored:
+                store(pis)
         else:
+            import time
+            t_db = time.perf_counter()
+            conn, c = db.create_probe_db(db_name)
             db.insert_tables(conn, c, files, all_tables, T, args.times, args.intervals)
-        conn.commit()
+            conn.commit()
+            c.close()
+            conn.close()
+            LAST_TIMINGS["sqlite"] = time.perf_counter() - t_db
         sys.stdout.write("DONE")
         sys.stdout.flush()
         print("\n")
-        c.close()
-        conn.close()
-        LAST_TIMINGS["sqlite"] = time.perf_counter() - t_db
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

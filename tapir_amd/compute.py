@@ -40,16 +40,16 @@ def round_like_hyphy(x, decimals=4):
     round_like_printf in csrc/pi_kernels.hpp."""
     x = np.asarray(x, dtype=np.float64)
     scale = 10.0 ** decimals
-    p = x * scale
-    n = np.rint(p)
-    out = n / scale
-    tie = np.flatnonzero(np.abs(p - n).reshape(-1) == 0.5)
-    if tie.size:
-        flat = out.reshape(-1)   # a view: out is a fresh contiguous array
-        src = x.reshape(-1)
-        for i in tie:
-            flat[i] = float("%.*f" % (decimals, src[i]))
-    return out
+    src = x.reshape(-1)
+    p = src * scale
+    out = np.rint(p)
+    np.subtract(p, out, out=p)   # in place: at C4 scale every temporary is 400 MB of pages touched for the first time
+    np.abs(p, out=p)
+    tie = np.flatnonzero(p == 0.5)
+    np.divide(out, scale, out=out)
+    for i in tie:
+        out[i] = float("%.*f" % (decimals, src[i]))
+    return out.reshape(x.shape) if x.ndim else out[0]
 
 
 def get_townsend_pi(time, rates, device=0):

@@ -229,6 +229,31 @@ def _write_job(job):
     return path
 
 
+class _SideThread:
+    """fn(arg) on a second thread; join() returns its seconds and raises what it raised."""
+
+    def __init__(self, fn, arg):
+        import threading
+        self.arg, self._fn, self._exc, self._seconds = arg, fn, None, 0.0
+        self._thread = threading.Thread(target=self._run, name="tapir_amd-side")
+        self._thread.start()
+
+    def _run(self):
+        import time
+        t0 = time.perf_counter()
+        try:
+            self._fn(self.arg)
+        except BaseException as exc:   # handed to the joining thread
+            self._exc = exc
+        self._seconds = time.perf_counter() - t0
+
+    def join(self):
+        self._thread.join()
+        if self._exc is not None:
+            raise self._exc
+        return self._seconds
+
+
 def _shared_dir(need_bytes=0):
     """/dev/shm when it is there, writable and has room for `need_bytes` (a tmpfs that fills up under a memory map kills
     the writer with SIGBUS: containers often give it 64 MB), else None."""
@@ -281,9 +306,15 @@ def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, bl
 
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
                    exch, pi=None, subsets=None, output_dir=None, device=0, integ_mode=0, round_decimals=4,
-                   engine_mod=None, progress=None, pool=None, cat_rates=None, cat_weights=None, start_rule=0):
+                   engine_mod=None, progress=None, pool=None, cat_rates=None, cat_weights=None, start_rule=0,
+                   during_write=None):
     """Site rates + PI for a list of NEXUS alignments.  Returns a list of worker()-shaped tuples
     (alignment, rates, mean_rate, None, pi_net, pi_times, pi_epochs) in the order of `alignments`.
+
+    during_write: callable(tuples) the caller would run next on the returned tuples (the command line: the sqlite
+    inserts).  When the pool's workers write the `.rates` files it runs on a second thread of this process meanwhile
+    (the parent only waits for the workers then; at C4 scale both take ~3 s) and out["during_write_done"] is True;
+    an exception it raises is raised here.  Otherwise it is not called.
 
     exch: [6] or [L,6] exchangeabilities AC,AG,AT,CG,CT,GT, or None = HyPhy's stage 1 (model-averaged estimates per
     locus, tapir_amd/stage1.py); pi: None (empirical, HarvestFrequencies) or [L,4].
@@ -352,15 +383,21 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
             total = int(offsets[-1])
             fd, shared = tempfile.mkstemp(prefix="tapir_amd_", suffix=".f64", dir=_shared_dir(32 * max(total, 1)))
             os.close(fd)
+            side = None
             try:
                 arr = np.memmap(shared, dtype=np.float64, mode="w+", shape=(4, max(total, 1)))
                 arr[0, :total], arr[1, :total], arr[2, :total], arr[3, :total] = out["subst"], rate4, out["lnl"], corrected
                 arr.flush()
                 jobs = [(paths[l], shared, max(total, 1), int(offsets[l]), int(offsets[l + 1]), pi[l], exch[l]) for l in range(L)]
+                if during_write is not None and not need_subset:
+                    side = _SideThread(during_write, _tuples(alignments, per_locus, out["tables"], T, times, intervals))
                 pool.write_rates(jobs, progress)
                 del arr
             finally:
                 os.unlink(shared)
+                if side is not None:
+                    timings["during_write"] = side.join()
+                    out["during_write_done"] = True
         else:
             for l in range(L):
                 sl = slice(offsets[l], offsets[l + 1])
@@ -377,6 +414,8 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
         tables = out["tables"]
     out["timings"] = timings
     out["final_tables"] = tables   # [L, W] rows as stored in sqlite (after any subset slicing)
+    if out.get("during_write_done"):
+        return side.arg, out
     return _tuples(alignments, per_locus, tables, T, times, intervals), out
 
 

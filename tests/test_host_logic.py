@@ -504,7 +504,9 @@ def test_shared_memory_files_need_room(tmp_path, monkeypatch):
 
 def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, oracle):
     """--multiprocessing (reference: Pool(cpu_count()-1), bin/tapir_compute.py:159-164) parallelises only the
-    host side; every output file must be identical to the sequential run."""
+    host side; every output file must be identical to the sequential run.  With the pool the sqlite inserts run on a
+    second thread while the workers write the `.rates` files (pipeline.run_alignments(during_write=...)): same rows in
+    all four tables, and what the side thread raises is raised by the call."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_engine
     from tapir_amd import cli, synth
@@ -520,6 +522,7 @@ def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, or
         cli.main([str(aln), str(tmp_path / "tree.newick"), "--output", str(out), "--times", "10,30", "--intervals", "5-15",
                   "--exchangeabilities", "1,1.2,0.8,0.9,1.5,1"] + flag, engine_mod=oracle_engine)
         outs.append(out)
+        assert ("during_write" in cli.LAST_TIMINGS) == bool(flag) and cli.LAST_TIMINGS["sqlite"] > 0
     names = sorted(os.listdir(outs[0]))
     assert names == sorted(os.listdir(outs[1])) and len(names) == 8
     for n in names:
@@ -529,6 +532,29 @@ def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, or
     a = sqlite3.connect(outs[0] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
     b = sqlite3.connect(outs[1] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
     assert a == b and len(a) == 6 * 100
+    for q, n in (("select * from loci order by id", 6), ("select * from discrete order by id, time", 12),
+                 ("select * from interval order by id, interval", 6)):
+        a = sqlite3.connect(outs[0] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
+        b = sqlite3.connect(outs[1] / "phylogenetic-informativeness.sqlite").execute(q).fetchall()
+        assert a == b and len(a) == n, q
+    # the side thread's failure surfaces in the caller, after the workers are done with the shared file
+    from tapir_amd import newick, pipeline
+    root = newick.read_tree(str(tmp_path / "tree.newick"), "newick")
+    leaf_names = [x.name for x in newick.leaves(root)]
+    parent, blen, leaf = newick.to_arrays(root, leaf_names)
+    files = sorted(str(aln / f) for f in os.listdir(aln) if f.endswith(".nex"))
+    out = tmp_path / "out_fail"
+    out.mkdir()
+
+    def fail(tuples):
+        assert len(tuples) == 6
+        raise RuntimeError("disk full")
+
+    with pipeline.HostPool(2) as pool:
+        with pytest.raises(RuntimeError, match="disk full"):
+            pipeline.run_alignments(files, leaf_names, parent, blen, leaf, 100, [10], [(5, 15)], 1.0, 3,
+                                    np.ones(6), output_dir=str(out), engine_mod=oracle_engine, pool=pool, during_write=fail)
+    assert len(os.listdir(out)) == 6 and not [f for f in os.listdir("/dev/shm") if f.startswith("tapir_amd_")]
 
 
 def test_stage1_model_enumeration():
