@@ -186,26 +186,50 @@ _ROW = ('            {\n                "site": ', ',\n                "subst": 
 _CROW = ('            {\n                "site": ', ',\n                "rate": ', '\n            },\n')
 
 
+_TEMPLATES = {}   # n -> the two arrays of a locus of n sites numbered 1..n with a %s for every number
+
+
+def _rates_template(n):
+    t = _TEMPLATES.get(n)
+    if t is None:
+        if len(_TEMPLATES) >= 32:   # ~150 bytes per site each; loci of one run mostly share a few lengths
+            _TEMPLATES.clear()
+        a, b, c, d, e = _ROW
+        rows = "".join([a + str(i) + b + "%s" + c + "%s" + d + "%s" + e for i in range(1, n + 1)])[:-2]
+        a, b, e = _CROW
+        crow = "".join([a + str(i) + b + "%s" + e for i in range(1, n + 1)])[:-2]
+        t = _TEMPLATES[n] = '        "rates": [\n%s\n        ],\n        "corrected_rates": [\n%s\n        ]\n' % (rows, crow)
+    return t
+
+
 def dumps_rates_json(freqs, exch, site, subst, rate, ll, corrected):
     """The text `json.dumps(format_rates_json(...), indent=4)` would produce, built by bulk string operations: the generic
-    encoder spends ~30 us per site (it dominated the whole CLI), a formatted row per site ~2 us, this ~0.6 us (every
-    per-site step -- rounding, repr, interleaving the fixed text -- runs inside numpy, map() or str.join)."""
+    encoder spends ~30 us per site (it dominated the whole CLI), a formatted row per site ~2 us, this ~1.2 us, of which
+    0.6 are the four float.__repr__ (every per-site step -- rounding, repr, placing the numbers in the fixed text -- runs
+    inside numpy, map() or one `%` over a template cached per number of sites; sites not numbered 1..n: str.join route)."""
     from itertools import chain, repeat
-    sub, rat, lls = _repr_rounded(subst), _repr_rounded(rate), _repr_rounded(ll)
-    cor = list(map(repr, np.ascontiguousarray(corrected, dtype=np.float64).reshape(-1).tolist()))   # json writes float.__repr__
-    sites = list(map(str, np.asarray(site).astype(np.int64).reshape(-1).tolist()))
     head = ('{\n    "sites": {\n        "freqs": {\n            "A": %s,\n            "C": %s,\n            "G": %s,\n'
             '            "T": %s\n        },\n        "subs_matrix": {\n            "AC": %s,\n            "AG": %s,\n'
             '            "AT": %s,\n            "CG": %s,\n            "CT": %s,\n            "GT": %s\n        },\n'
             % tuple(repr(float(x)) for x in list(freqs) + list(exch)))
-    if sites:
+    site = np.asarray(site).astype(np.int64).reshape(-1)
+    n = site.size
+    cor = map(repr, np.ascontiguousarray(corrected, dtype=np.float64).reshape(-1).tolist())   # json writes float.__repr__
+    if n == 0:
+        body = '        "rates": [],\n        "corrected_rates": []\n'
+    elif site[0] == 1 and site[-1] == n and np.array_equal(site, np.arange(1, n + 1)):
+        cols = [np.asarray(v, dtype=np.float64).reshape(-1) for v in (subst, rate, ll)]
+        vals = _repr_rounded(np.stack(cols, axis=1))   # subst, rate, ll of site 1, of site 2, ...
+        vals.extend(cor)
+        body = _rates_template(n) % tuple(vals)
+    else:
+        sub, rat, lls = _repr_rounded(subst), _repr_rounded(rate), _repr_rounded(ll)
+        sites = list(map(str, site.tolist()))
         a, b, c, d, e = _ROW
         rows = "".join(chain.from_iterable(zip(repeat(a), sites, repeat(b), sub, repeat(c), rat, repeat(d), lls, repeat(e))))[:-2]
         a, b, e = _CROW
         crow = "".join(chain.from_iterable(zip(repeat(a), sites, repeat(b), cor, repeat(e))))[:-2]
         body = '        "rates": [\n%s\n        ],\n        "corrected_rates": [\n%s\n        ]\n' % (rows, crow)
-    else:
-        body = '        "rates": [],\n        "corrected_rates": []\n'
     return head + body + "    }\n}"
 
 

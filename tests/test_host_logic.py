@@ -442,6 +442,16 @@ def test_fast_rates_writer_is_byte_identical_to_json_dump():
     site = np.arange(1, len(v) + 1)
     a = json.dumps(pipeline.format_rates_json(pi, ex, site, v, v, -v, v / 100), indent=4)
     assert pipeline.dumps_rates_json(pi, ex, site, v, v, -v, v / 100) == a
+    # sites not numbered 1..n do not fit the cached template of a locus of n sites
+    for site in (np.arange(5, 5 + len(v)), np.arange(len(v), 0, -1), np.r_[1, np.arange(3, len(v) + 1), len(v)]):
+        a = json.dumps(pipeline.format_rates_json(pi, ex, site, v, v, -v, v / 100), indent=4)
+        assert pipeline.dumps_rates_json(pi, ex, site, v, v, -v, v / 100) == a
+    # more distinct lengths than the template cache keeps
+    for n in range(2, 80):
+        x = rng.gamma(1, 1, n)
+        a = json.dumps(pipeline.format_rates_json(pi, ex, np.arange(1, n + 1), x, x, -x, x / 7), indent=4)
+        assert pipeline.dumps_rates_json(pi, ex, np.arange(1, n + 1), x, x, -x, x / 7) == a
+    assert 0 < len(pipeline._TEMPLATES) <= 32
 
 
 def test_pool_parses_alignments_straight_into_the_batch_array(tmp_path):
