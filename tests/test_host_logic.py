@@ -564,7 +564,9 @@ def test_cli_multiprocessing_flag_gives_identical_files(golden_dir, tmp_path, or
         with pytest.raises(RuntimeError, match="disk full"):
             pipeline.run_alignments(files, leaf_names, parent, blen, leaf, 100, [10], [(5, 15)], 1.0, 3,
                                     np.ones(6), output_dir=str(out), engine_mod=oracle_engine, pool=pool, during_write=fail)
-    assert len(os.listdir(out)) == 6 and not [f for f in os.listdir("/dev/shm") if f.startswith("tapir_amd_")]
+    assert len(os.listdir(out)) == 6
+    if os.path.isdir("/dev/shm"):
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith("tapir_amd_")]
 
 
 def test_stage1_model_enumeration():
