@@ -254,11 +254,11 @@ def _write_job(job):
 
 
 class _SideThread:
-    """fn(arg) on a second thread; join() returns its seconds and raises what it raised."""
+    """fn(make_arg()) on a second thread, the argument kept in .arg; join() returns its seconds and raises what it raised."""
 
-    def __init__(self, fn, arg):
+    def __init__(self, fn, make_arg):
         import threading
-        self.arg, self._fn, self._exc, self._seconds = arg, fn, None, 0.0
+        self.arg, self._make_arg, self._fn, self._exc, self._seconds = None, make_arg, fn, None, 0.0
         self._thread = threading.Thread(target=self._run, name="tapir_amd-side")
         self._thread.start()
 
@@ -266,6 +266,7 @@ class _SideThread:
         import time
         t0 = time.perf_counter()
         try:
+            self.arg = self._make_arg()
             self._fn(self.arg)
         except BaseException as exc:   # handed to the joining thread
             self._exc = exc
@@ -414,7 +415,7 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
                 arr.flush()
                 jobs = [(paths[l], shared, max(total, 1), int(offsets[l]), int(offsets[l + 1]), pi[l], exch[l]) for l in range(L)]
                 if during_write is not None and not need_subset:
-                    side = _SideThread(during_write, _tuples(alignments, per_locus, out["tables"], T, times, intervals))
+                    side = _SideThread(during_write, lambda: _tuples(alignments, per_locus, out["tables"], T, times, intervals))
                 pool.write_rates(jobs, progress)
                 del arr
             finally:
