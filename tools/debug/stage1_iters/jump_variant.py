@@ -1,4 +1,4 @@
-import sys, time, inspect, numpy as np
+import os, sys, time, inspect, numpy as np
 from harness import *
 src = inspect.getsource(stage1._LBFGS)
 # 1) coordinates (>= 5: log branch lengths) whose Newton step in b itself reaches zero jump to the lower bound
@@ -34,6 +34,18 @@ new = '''            s_ = np.where(jump, 0.0, xnew - xl)
 assert old in src; src = src.replace(old, new)
 old = "                gamma = gamma[keep]\n"
 assert old in src; src = src.replace(old, old + "                jump = jump[keep]\n")
+if os.environ.get("ANYTIME_ESCAPE"):   # the escape test on every iteration (not only at stopping points), history kept
+    o = "            if stop.any() and self.escape is not None:\n"
+    assert o in src
+    src = src.replace(o, "            if self.escape is not None:\n                stop_real = stop\n                stop = np.ones_like(stop)\n")
+    o = """                    rho[:, mi] = 0.0
+                    nhist[mi] = 0
+                    last_df[mi] = np.inf
+                    continue          # recompute every direction from the new points"""
+    assert o in src
+    src = src.replace(o, """                    last_df[mi] = np.inf
+                    continue          # recompute every direction from the new points
+                stop = stop_real""")
 ns = dict(vars(stage1)); ns["JUMP"] = True; ns["JUMP_FRAC"] = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0; ns["JUMP_BELOW"] = float(sys.argv[4]) if len(sys.argv) > 4 else -5.0
 exec(src, ns)
 NewLBFGS = ns["_LBFGS"]
