@@ -29,12 +29,16 @@ def fitch_branch_changes(states, parent, leaf):
     low = lambda m: m & (~m + 1).astype(np.uint8) if False else (m & (-m.astype(np.int16)).astype(np.uint8))
     chosen = [None] * nn
     changes = np.zeros(nn)
+    pairs = np.zeros((4, 4))
     chosen[root] = low(sets[root])
+    bit = np.zeros(16, np.int64); bit[[1, 2, 4, 8]] = [0, 1, 2, 3]
     for v in order[1:]:
         p = parent[v]
         keep = (sets[v] & chosen[p]) != 0
         chosen[v] = np.where(keep, chosen[p], low(sets[v]))
         changes[v] = (~keep).sum()
+        np.add.at(pairs, (bit[chosen[p][~keep]], bit[chosen[v][~keep]]), 1.0)
+    fitch_branch_changes.pairs = pairs + pairs.T
     return changes
 
 class S1(stage1.Stage1):
@@ -47,7 +51,29 @@ class S1(stage1.Stage1):
             ch = fitch_branch_changes(st, self.plan.parent, self.plan.leaf)
             b = np.maximum(ch, FLOOR) / max(st.shape[1], 1)
             out[l, self.branches] = b[self.branches] / tf[l]
+            pr = fitch_branch_changes.pairs
+            pi = self.pi[l]
+            r = np.array([(pr[i, j] + 0.5) / (pi[i] * pi[j]) for i, j in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))])
+            self.rate_start[l] = np.log(np.clip(r / r[1], 0.05, 20.0))[[0, 2, 3, 4, 5]]
         return out
+
+    def fit_grm(self, maxit=None):
+        self.rate_start = np.zeros((self.plan.nloci, 5))
+        if not os.environ.get("RATE_START"):
+            return super().fit_grm(maxit)
+        # same as the parent's, with the five log-rates started from the parsimony pair counts
+        real = stage1._LBFGS
+        outer = self
+        class Wrapped(real):
+            def __init__(self, value, vg, x0, **k):
+                x0 = np.array(x0); x0[:, :5] = outer.rate_start
+                # b = t * totalFactor: lengths were divided by totalFactor(ones); keep b as it is
+                super().__init__(value, vg, x0, **k)
+        stage1._LBFGS = Wrapped
+        try:
+            return super().fit_grm(maxit)
+        finally:
+            stage1._LBFGS = real
 
 if __name__ == "__main__":
     nloci, ncols, ntaxa = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
