@@ -223,6 +223,44 @@ int tphip_locus_gradient_dev(tphip_plan *plan, const uint8_t *d_states, int64_t 
                              double *d_lnl, double *d_dexch, double *d_dlogt, double *d_sum_dlogt, double *d_d2logt,
                              void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * HyPhy's stage 1 as one call: model-averaged exchangeabilities for every locus of the plan.
+ * Replaces, per locus, models_and_rates.bf:487-520 (general reversible model: Optimize over AC, AT, CG, CT, GT
+ * and every branch length), :522-540 (branch lengths stashed as expected substitutions), :542-661 (the other 202
+ * partitions of the six rates into classes, Optimize over at most four class rates each) and :806-847 (Akaike weights
+ * w_m ~ exp(lnL_m - k_m), model-averaged rates).  The optimisers run on the device (stage1_opt_kernels.hpp: L-BFGS for
+ * the general model, dense BFGS for the rate-class models, a quadratic screen that decides which of the 202 can carry
+ * weight); the host sequences launches.  The plan's own exchangeabilities are ignored, its pi and tree are used; with
+ * column weights set (tphip_plan_set_column_weights) the plan's columns are site patterns, as HyPhy evaluates them.
+ * Models are indexed 0..202: 0 = "012345" (the general model), then the other restricted growth strings over
+ * (AC, AG, AT, CG, CT, GT) in lexicographic order = the order of the loops at bf:544-566.
+ * Outputs are HOST arrays (the call synchronises `stream` before it returns); all but exch may be NULL:
+ *   exch[L][6]           model-averaged AC, AG (= 1), AT, CG, CT, GT -- what stage 2 takes (bf:838-847)
+ *   weights[L][203]      Akaike weights;  lnl[L][203] maximised log-likelihoods;  model_exch[L][203][6] fitted rates
+ *   grm_blen[L][nnodes]  branch lengths t_b of the general model (stash / totalFactor)
+ *   grm_iters[L], sub_iters[L][202]  optimiser iterations;  stats[8] = likelihood evaluations, gradients, evaluations and
+ *                        gradients of the general model, models abandoned, models fitted, outer iterations (general, class) */
+typedef struct tphip_stage1_opts {
+    uint32_t struct_size;   /* sizeof(tphip_stage1_opts) as the caller compiled it; fields beyond it take their defaults.
+                               Zero-initialise the struct, then set this.                                          */
+    int32_t maxit_grm;      /* iteration limit of the general model, 0 = max(300, 4 * (5 + branches))              */
+    int32_t maxit_sub;      /* iteration limit of a rate-class model, 0 = 100                                      */
+    int32_t no_prune;       /* 1 = fit all 202 models to convergence (default 0: a model whose Akaike weight cannot
+                               exceed e^-21 is abandoned with the likelihood it has reached, a lower bound)          */
+    double fd_step;         /* step of the central differences of the rate-class fits in log-rate, 0 = 1e-4         */
+    int32_t free_root_pair; /* 1 = the two branches below a bifurcating root are separate coordinates, as in HyPhy's
+                               parameter list (default 0: one coordinate for their sum, which is all a reversible
+                               model's likelihood depends on; the reported pair keeps the input tree's proportion)  */
+} tphip_stage1_opts;
+
+int tphip_stage1_fit_dev(tphip_plan *plan, const uint8_t *d_states, const tphip_stage1_opts *opts, double *exch,
+                         double *weights, double *lnl, double *model_exch, double *grm_blen, int32_t *grm_iters,
+                         int32_t *sub_iters, int64_t *stats, void *stream);
+/* host-pointer twin: `states` is uploaded (and its state codes packed) once; d_states_cache as for tphip_locus_loglik */
+int tphip_stage1_fit(tphip_plan *plan, const uint8_t *states, void **d_states_cache, const tphip_stage1_opts *opts,
+                     double *exch, double *weights, double *lnl, double *model_exch, double *grm_blen,
+                     int32_t *grm_iters, int32_t *sub_iters, int64_t *stats);
+
 /* Profiling hooks for bench.py: when enabled the library brackets its dominant kernel (site rates) with
  * HIP events on the caller's stream and accumulates the elapsed time. */
 int tphip_profile_enable(tphip_plan *plan, int32_t on);

@@ -36,6 +36,11 @@ class PlanDesc(ctypes.Structure):
                 ("pattern_dedup", _i32)]
 
 
+class Stage1Opts(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("maxit_grm", _i32), ("maxit_sub", _i32), ("no_prune", _i32),
+                ("fd_step", _f64), ("free_root_pair", _i32)]
+
+
 # every symbol include/tphip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("tphip_version", ctypes.c_int, []),
@@ -79,6 +84,8 @@ SYMBOLS = [
     ("tphip_compress_columns", ctypes.c_int, [ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     ("tphip_locus_gradient", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 11),
     ("tphip_free_device", ctypes.c_int, [_vp, _vp]),
+    ("tphip_stage1_fit_dev", ctypes.c_int, [_vp, _vp, ctypes.POINTER(Stage1Opts)] + [_vp] * 9),
+    ("tphip_stage1_fit", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(Stage1Opts)] + [_vp] * 8),
 ]
 
 _lib = None
@@ -372,6 +379,31 @@ class Plan:
                                               lnl.ctypes.data, dex.ctypes.data, dlt.ctypes.data if per_branch else None,
                                               st.ctypes.data, d2.ctypes.data if curvature else None))
         return (lnl, dex, dlt, st, d2) if curvature else (lnl, dex, dlt, st)
+
+    def stage1_fit(self, states, cache=None, details=True, maxit_grm=0, maxit_sub=0, prune_models=True, fd_step=0.0,
+                   free_root_pair=False):
+        """HyPhy's stage 1 for every locus of the plan in one engine call (tphip_stage1_fit): model-averaged
+        exchangeabilities [L, 6] and, with details, weights / lnl [L, 203], model_exch [L, 203, 6], grm_blen [L, nnodes],
+        iteration counts and counters.  The optimisers run on the device (csrc/stage1_opt_kernels.hpp)."""
+        states = _np(states, np.uint8)
+        assert states.shape == (self.ntaxa, self.ncols), (states.shape, self.ntaxa, self.ncols)
+        L, nn = self.nloci, len(self._keep["parent"])
+        opts = Stage1Opts(struct_size=ctypes.sizeof(Stage1Opts), maxit_grm=int(maxit_grm), maxit_sub=int(maxit_sub),
+                          no_prune=0 if prune_models else 1, fd_step=float(fd_step),
+                          free_root_pair=1 if free_root_pair else 0)
+        out = dict(exch=np.empty((L, 6)))
+        if details:
+            out.update(weights=np.empty((L, 203)), lnl=np.empty((L, 203)), model_exch=np.empty((L, 203, 6)),
+                       grm_blen=np.empty((L, nn)), grm_iters=np.empty(L, np.int32), sub_iters=np.empty((L, 202), np.int32))
+        stats = np.zeros(8, np.int64)
+        ref = ctypes.byref(cache.ptr) if cache is not None else None
+        g = lambda k: out[k].ctypes.data if k in out else None  # noqa: E731
+        _check(self._lib.tphip_stage1_fit(self._h, states.ctypes.data, ref, ctypes.byref(opts), out["exch"].ctypes.data,
+                                          g("weights"), g("lnl"), g("model_exch"), g("grm_blen"), g("grm_iters"),
+                                          g("sub_iters"), stats.ctypes.data))
+        out["stats"] = dict(zip(("nevals", "ngrads", "grm_evals", "grm_grads", "pruned", "fitted", "grm_outer_iterations",
+                                 "sub_outer_iterations"), stats.tolist()))
+        return out
 
     def set_column_weights(self, weights):
         """Column multiplicities for locus_loglik / locus_gradient (site-pattern counts); None removes them."""

@@ -706,8 +706,20 @@ class Stage1:
                     models=model_strings(), nevals=self.nevals, ngrads=self.ngrads)
 
 
-def model_averaged_exchangeabilities(plan, states, pi, parent, blen, **kw):
-    """Convenience wrapper: returns dict with `exch` [L, 6] (AC, AG=1, AT, CG, CT, GT) and diagnostics."""
+def model_averaged_exchangeabilities(plan, states, pi, parent, blen, engine_fit=None, **kw):
+    """Returns dict with `exch` [L, 6] (AC, AG=1, AT, CG, CT, GT) and diagnostics.
+
+    The product path is ONE engine call, tphip_stage1_fit (csrc/stage1_driver.hip: the optimisers are device kernels,
+    the host sequences launches).  engine_fit=False -- or any option of the class below -- runs this module's host
+    optimiser over the same likelihood kernels instead: the round-1/2 implementation, kept as a second opinion for
+    tests and A/B timing (tools/stage1_timing.py host)."""
+    if engine_fit is None:
+        engine_fit = hasattr(plan, "stage1_fit") and not kw and os.environ.get("TPHIP_STAGE1_HOST") is None
+    if engine_fit:
+        out = plan.stage1_fit(states)
+        st = out.pop("stats")
+        out.update(models=model_strings(), nevals=st["nevals"], ngrads=st["ngrads"], stats=st)
+        return out
     s1 = Stage1(plan, states, pi, parent, blen, **kw)
     try:
         return s1.run()
