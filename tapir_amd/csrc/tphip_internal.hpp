@@ -152,7 +152,9 @@ struct tphip_plan {
 };
 
 // helpers of tphip.hip for the other translation units of the library (not declared in include/tphip.h)
+// (hidden visibility: the shared library exports exactly what include/tphip.h declares)
 extern "C" {
-int tphip_internal_stage_alignment(tphip_plan* p, const uint8_t* states, void** d_states_cache, uint8_t** d_s);
-const tphip_plan_desc* tphip_internal_saved_desc(const tphip_plan* p);
+__attribute__((visibility("hidden"))) int tphip_internal_stage_alignment(tphip_plan* p, const uint8_t* states, void** d_states_cache,
+                                                                       uint8_t** d_s);
+__attribute__((visibility("hidden"))) const tphip_plan_desc* tphip_internal_saved_desc(const tphip_plan* p);
 }

@@ -1,6 +1,7 @@
-"""HyPhy stage 1 on the GPU: model-averaged GTR exchangeabilities per locus.
+"""HyPhy stage 1 (model-averaged GTR exchangeabilities per locus, models_and_rates.bf:405-897): entry point and a
+second-opinion host optimiser.
 
-What it replaces (tapir/data/models_and_rates.bf, "next" row #1 of SURVEY.md section 8f):
+What stage 1 is (tapir/data/models_and_rates.bf, "next" row #1 of SURVEY.md section 8f):
 
   bf:487-520   general reversible model (012345): `Optimize(lf_MLES, lf)` over the 5 exchangeabilities
                AC, AT, CG, CT, GT (AG = 1) AND every branch length;
@@ -13,10 +14,13 @@ What it replaces (tapir/data/models_and_rates.bf, "next" row #1 of SURVEY.md sec
                k_m = number of free rates (everything else in np_m is the same for all models);
   bf:838-847   modelAveragedRates[v] = sum_m w_m rate_m[v]  ->  the AC, AT, CG, CT, GT handed to stage 2.
 
-Division of labour: every likelihood is evaluated on the GPU by `locus_loglik_kernel` (one workgroup per
-(locus, candidate point)); this module is the optimiser around it, written once for ALL loci (and all 202
-models) at a time in numpy: batched L-BFGS on log-parameters with central-difference gradients.  A finite
-difference stencil costs no extra branch-length storage (the kernel perturbs one branch of a shared vector).
+The PRODUCT path is one engine call, `Plan.stage1_fit` -> tphip_stage1_fit (csrc/stage1_driver.hip +
+csrc/stage1_opt_kernels.hpp): likelihoods, gradients AND the optimisers are device kernels, the host sequences
+launches; `model_averaged_exchangeabilities` below goes there.
+
+The `Stage1` class is the round-1/2 implementation -- the same likelihood kernels driven by a batched L-BFGS written in
+numpy -- kept as an independent second opinion for the tests (tests/test_gpu_stage1.py) and for A/B timing
+(tools/stage1_timing.py compare).  It is not on the product path.
 
 Parity: HyPhy's own optimiser and its results for this stage are pinned by no fixture of the reference
 ("parity unpinned"); the stage is checked against an independent CPU restatement
@@ -36,7 +40,6 @@ LOG_BLEN_MIN, LOG_BLEN_MAX = -23.0, 4.0     # branch lengths within [1e-10, 55]
 MAX_LOG_STEP = 2.0                          # largest move of a log-parameter in one iteration
 ESCAPE_RATE = 0.05                          # where a wrongly collapsed exchangeability is put back (Stage1._sub_escape)
 ESCAPE_LENGTH = 1e-3                        # where a wrongly collapsed branch is put back (Stage1._grm_escape)
-DEVICE_GRM_MIN_SIZE = 250000                # loci x parameters from which the general model is fitted by the device L-BFGS
 PRUNE_NATS = 21.0                           # see Stage1.fit_submodels: a model this far behind weighs < e^-21 = 8e-10
 _PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # AC AG AT CG CT GT as (i, j) over A C G T
 
@@ -264,11 +267,8 @@ class Stage1:
     """Model-averaged exchangeabilities for every locus of a plan (see module docstring)."""
 
     def __init__(self, plan, states, pi, parent, blen, fd_step=1e-4, analytic=None, sub_analytic=None, prune_models=True,
-                 precondition=True, verbose=False, screen_models=True, device_fit=True):
+                 precondition=True, verbose=False, screen_models=True):
         self.screen_models = screen_models   # quadratic screen of the 202 constrained models (see _screen_submodels)
-        self.device_fit = device_fit         # fit the surviving models with the device-resident optimiser (stage1_device.py)
-        self.sub_device = False
-        self.grm_device = False
         self.plan, self.states = plan, np.ascontiguousarray(states, dtype=np.uint8)
         self.pi = np.asarray(pi, dtype=np.float64).reshape(plan.nloci, 4)
         self.pi = self.pi / self.pi.sum(1, keepdims=True)
@@ -433,22 +433,10 @@ class Stage1:
         lo = np.concatenate([np.full(5, LOG_RATE_MIN), np.full(len(self.branches), LOG_BLEN_MIN)])
         hi = np.concatenate([np.full(5, LOG_RATE_MAX), np.full(len(self.branches), LOG_BLEN_MAX)])
         self._kicks = np.zeros(L, dtype=np.int64)
-        from . import stage1_device
-        big = x0.size >= DEVICE_GRM_MIN_SIZE or self.device_fit == "always"
-        if self.device_fit and big and self.analytic and self.precondition and stage1_device.available(self.plan) and self.cache.ptr:
-            # L-BFGS state on the GPU (stage1_device.DeviceLBFGS): same iteration, no numpy in the loop.  Only for large
-            # batches: an iteration is ~100 small torch launches (~7 ms), numpy's is cheaper below ~2000 loci x 131
-            # parameters (measured: 2000 x 1000 x 64 taxa 1.69 -> 1.35 s, but C2 shape 0.14 -> 0.46 s, 32 x 50 000 0.30 -> 0.53 s)
-            fit = stage1_device.DeviceGrmFitter(self.plan, self.cache.ptr.value, self.pi, self.branches, self.nn, device=self.plan.device)
-            x, f, self.grm_iters = fit.fit(x0, lo, hi, maxit)
-            self.nevals += fit.nevals
-            self.ngrads += fit.ngrads
-            self.grm_device = True
-        else:
-            opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi,
-                         escape=self._grm_escape if self.analytic else None)
-            x, f = opt.run()
-            self.grm_iters = opt.iters
+        opt = _LBFGS(self._grm_value, self._grm_value_and_grad, x0, maxit=maxit, lo=lo, hi=hi,
+                     escape=self._grm_escape if self.analytic else None)
+        x, f = opt.run()
+        self.grm_iters = opt.iters
         exch = self._exch_from_free(x[:, :5])
         t = np.zeros((L, self.nn))
         t[:, self.branches] = np.exp(x[:, 5:]) / total_factor(self.pi, exch)[:, None]
@@ -659,23 +647,11 @@ class Stage1:
                 self.pruned += int(drop.sum())
                 return drop
 
-            from . import stage1_device
-            if self.device_fit and not self.sub_analytic and self._sub_hdiag is not None and stage1_device.available(self.plan) \
-                    and self.cache.ptr:
-                # optimiser state on the GPU (stage1_device.py): no host round trip per likelihood call
-                fit = stage1_device.DeviceSubmodelFitter(self.plan, self.cache.ptr.value, self._stash, self._w6, self._sub_locus,
-                                                         self._sub_cls, self._sub_active, self._sub_stencil, self._sub_need,
-                                                         kk_sel, self.h, device=self.plan.device)
-                xs, fs, its = fit.run(x0[sel], self._sub_hdiag, best, maxit=maxit, prune=self.prune_models)
-                self.nevals += fit.nevals
-                self.pruned += fit.pruned
-                self.sub_device = True
-            else:
-                opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0[sel], active=self._sub_active, maxit=maxit,
-                             lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune_sel if self.prune_models else None,
-                             escape=self._sub_escape)
-                xs, fs = opt.run()
-                its = opt.iters
+            opt = _LBFGS(self._sub_value, self._sub_value_and_grad, x0[sel], active=self._sub_active, maxit=maxit,
+                         lo=LOG_RATE_MIN, hi=LOG_RATE_MAX, prune=prune_sel if self.prune_models else None,
+                         escape=self._sub_escape)
+            xs, fs = opt.run()
+            its = opt.iters
             x[sel], fall[sel] = xs, fs
             self.sub_iters[sel] = its
             self._sub_cls, self._sub_locus, self._sub_active = full["cls"], full["locus"], full["active"]
@@ -718,7 +694,7 @@ def model_averaged_exchangeabilities(plan, states, pi, parent, blen, engine_fit=
     if engine_fit:
         out = plan.stage1_fit(states)
         st = out.pop("stats")
-        out.update(models=model_strings(), nevals=st["nevals"], ngrads=st["ngrads"], stats=st)
+        out.update(models=model_strings(), nevals=st["nevals"], ngrads=st["ngrads"], stats=st, grm_exch=out["model_exch"][:, 0])
         return out
     s1 = Stage1(plan, states, pi, parent, blen, **kw)
     try:

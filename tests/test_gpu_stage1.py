@@ -95,8 +95,10 @@ def test_cli_default_model_averaging_on_gpu(tmp_path):
 
 
 def test_stage1_analytic_and_finite_difference_gradients_agree():
-    """The optimiser driven by the reverse-mode gradient kernel reaches the same model-averaged rates as the one
-    driven by central differences of the value kernel."""
+    """Second opinions on the engine's stage 1 (tphip_stage1_fit): the host optimiser of tapir_amd/stage1.py driven by the
+    reverse-mode gradient kernel and the same optimiser driven by central differences of the value kernel reach the same
+    model-averaged rates (1e-3, lnL 1e-3, weights 1e-4), the engine reaches them too, and abandoning hopeless models early
+    changes nothing in what the engine reports (1e-6) while saving likelihood evaluations."""
     engine = _engine()
     from tapir_amd import stage1, synth
     L, n, nt = 4, 400, 12
@@ -109,13 +111,17 @@ def test_stage1_analytic_and_finite_difference_gradients_agree():
                        [1], [[0, 1]], correction=pin["correction"])
     a = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen, analytic=True, prune_models=False)
     b = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen, analytic=False, prune_models=False)
-    c = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen)   # defaults: early abandoning on
+    c = stage1.model_averaged_exchangeabilities(plan, st, pi, pin["parent"], blen)   # the product path: one engine call
+    e = plan.stage1_fit(st, prune_models=False)
     plan.close()
-    assert a["ngrads"] > 0 and b["ngrads"] == 0
-    assert np.max(np.abs(c["exch"] - a["exch"]) / a["exch"]) < 1e-6 and c["nevals"] < b["nevals"]
+    assert a["ngrads"] > 0 and b["ngrads"] == 0 and c["ngrads"] > 0
+    assert np.max(np.abs(c["exch"] - e["exch"]) / e["exch"]) < 1e-6 and c["nevals"] < e["stats"]["nevals"] < b["nevals"]
     assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-3
     assert np.max(np.abs(a["lnl"] - b["lnl"])) < 1e-3
     assert np.max(np.abs(a["weights"] - b["weights"])) < 1e-4
+    assert np.max(np.abs(e["exch"] - a["exch"]) / a["exch"]) < 1e-3
+    assert np.max(np.abs(e["weights"] - a["weights"])) < 1e-4
+    assert np.all(e["lnl"] >= a["lnl"] - 1e-3)      # the engine never ends below the host optimiser
 
 
 def test_stage1_on_the_bundled_locus_vs_restatement_and_phydesign():
@@ -142,11 +148,12 @@ def test_stage1_on_the_bundled_locus_vs_restatement_and_phydesign():
     assert np.max(np.abs(got[0] - want) / want) < 0.06
 
 
-def test_stage1_device_fitter_matches_host_fitter():
-    """The constrained models are fitted by the device-resident optimiser (tapir_amd/stage1_device.py: state in HBM, dense
-    BFGS per problem, no host round trip per likelihood call) by default; the numpy L-BFGS of stage1.py is the same
-    computation on the host.  Both must reach the same optima: averaged rates 1e-5, weights 1e-6, lnL of every model that
-    carries weight 1e-5 -- on short loci (many models matter) and on long ones (a handful)."""
+def test_stage1_engine_matches_host_optimiser():
+    """The engine's optimisers (csrc/stage1_opt_kernels.hpp: L-BFGS and dense BFGS as device kernels, sequenced by
+    csrc/stage1_driver.hip) against the numpy optimiser of stage1.py over the same likelihood kernels -- on short loci
+    (many models matter) and on long ones (a handful).  Both must reach the same optima: averaged rates 1e-3 (the stage's
+    tolerance; observed 3e-5), weights 1e-4, and the engine's log-likelihoods are never below the host's by more than its own
+    stopping tolerance (it may be above: its metric for short branches finds optima the host optimiser stops short of)."""
     engine = _engine()
     from tapir_amd import stage1, synth
     for L, n, nt, seed in ((12, 300, 10, 41), (3, 6000, 16, 42)):
@@ -157,19 +164,26 @@ def test_stage1_device_fitter_matches_host_fitter():
         blen = np.asarray(pin["blen"]) / pin["correction"]
         plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"],
                            [1], [[0, 1]], correction=pin["correction"])
-        s_dev = stage1.Stage1(plan, st, pi, pin["parent"], blen, device_fit="always")   # general model on the device too
-        a = s_dev.run()
-        assert s_dev.sub_device and s_dev.grm_device, "the device fitters did not run"
-        s_dev.close()
-        s_host = stage1.Stage1(plan, st, pi, pin["parent"], blen, device_fit=False)
+        a = plan.stage1_fit(st)
+        a2 = plan.stage1_fit(st, free_root_pair=True)   # HyPhy's parameter list: both branches below the root free
+        s_host = stage1.Stage1(plan, st, pi, pin["parent"], blen)
         b = s_host.run()
-        assert not s_host.sub_device and not s_host.grm_device
         s_host.close()
         plan.close()
-        assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-5
-        assert np.max(np.abs(a["weights"] - b["weights"])) < 1e-6
+        assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-3
+        assert np.max(np.abs(a["weights"] - b["weights"])) < 1e-4
         heavy = b["weights"] > 1e-8
-        assert np.max(np.abs(a["lnl"] - b["lnl"])[heavy]) < 1e-5
+        # a rate-class fit stops when its Newton model predicts a gain below 1e-9 (1 + |lnL|) (sub_direction_kernel); the
+        # host optimiser always polishes one iteration further
+        short = (b["lnl"] - a["lnl"])[heavy]
+        assert short.max() < 1e-5 + 3e-9 * np.abs(b["lnl"][heavy]).max(), short.max()
+        assert np.max(np.abs(a["lnl"] - b["lnl"])[heavy]) < 1e-3
+        # the likelihood of a reversible model sees only the SUM of the two branches below the root
+        assert np.max(np.abs(a2["lnl"][:, 0] - a["lnl"][:, 0])) < 1e-4 and np.max(np.abs(a2["exch"] - a["exch"]) / a["exch"]) < 1e-4
+        par = np.asarray(pin["parent"])
+        rk = np.flatnonzero(par == len(par) - 1)
+        if len(rk) == 2:
+            assert np.allclose(a["grm_blen"][:, rk].sum(1), a2["grm_blen"][:, rk].sum(1), rtol=1e-3, atol=1e-9)
 
 
 def test_stage1_degenerate_loci_stay_finite():
@@ -229,7 +243,7 @@ def test_stage1_fullsize_properties():
     lo, hi = res["model_exch"].min(axis=1), res["model_exch"].max(axis=1)
     assert np.all(exch >= lo - 1e-12) and np.all(exch <= hi + 1e-12)
     # stationarity of the general model in (log rates, log lengths)
-    ge, gt = res["grm_exch"], res["grm_blen"]
+    ge, gt = res["model_exch"][:, 0], res["grm_blen"]
     val, dex, dlt, _ = plan.locus_gradient(st, gt, np.arange(L), ge)
     assert np.max(np.abs(val - lnl[:, 0]) / np.abs(val)) < 1e-9
     br = np.asarray(pin["parent"]) >= 0

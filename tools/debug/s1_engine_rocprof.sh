@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp
 for shape in "$@"; do
   tag=$(echo $shape | tr ' ' x)
-  timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- python3 $R/tools/stage1_engine_timing.py $shape reps=2 > $OUT/$tag.log 2>&1 || { echo "$tag failed"; tail -5 $OUT/$tag.log; exit 1; }
+  timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -- python3 $R/tools/stage1_timing.py $shape reps=2 > $OUT/$tag.log 2>&1 || { echo "$tag failed"; tail -5 $OUT/$tag.log; exit 1; }
   cp $(ls $OUT/$tag/*/*kernel_stats.csv | head -1) $OUT/${tag}_kernel_stats.csv
   tail -2 $OUT/$tag.log
   rm -rf $OUT/$tag
