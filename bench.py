@@ -340,23 +340,26 @@ def stage1_sample(data, pin, nl, ncols, ntaxa, times, intervals):
     """Not part of `value`: wall time of the stage that precedes the per-site loop in HyPhy's script (203-model fit +
     Akaike averaging of the exchangeabilities, models_and_rates.bf:405-897) on the first loci of the same batch, through
     the product path (pattern compression, likelihood + gradient kernels, tapir_amd/stage1.py)."""
-    from tapir_amd import engine, nexus, pipeline
-    st = data["states"][:, :nl * ncols].cpu().numpy()
+    from tapir_amd import engine, pipeline
+    # the alignment sits in pinned host memory, as the command line's parser leaves it (pipeline.load_alignments)
+    st = engine.pinned_empty((ntaxa, nl * ncols), np.uint8)
+    st[:] = data["states"][:, :nl * ncols].cpu().numpy()
     off = np.arange(nl + 1, dtype=np.int64) * ncols
 
     def run():
         t0 = time.perf_counter()
-        pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, off))
-        e = pipeline.model_averaged_exchangeabilities(engine, st, off, pi, ntaxa, pin["parent"], pin["blen"], pin["leaf"],
+        # one engine call: upload, empirical base frequencies (bf:968), site patterns (bf:960-963), the 203 fits, averaging
+        e = pipeline.model_averaged_exchangeabilities(engine, st, off, None, ntaxa, pin["parent"], pin["blen"], pin["leaf"],
                                                       pin["T"], times, intervals, pin["correction"])
         return e, time.perf_counter() - t0
 
-    _, first = run()       # the first call of a process also loads torch's kernels for the device-resident optimisers (~0.2 s)
+    _, first = run()
     exch, dt = run()
     true = np.asarray(data["exch"][:nl])
     return {"loci": nl, "columns": nl * ncols, "seconds": dt, "columns_per_s": nl * ncols / dt, "first_call_seconds": first,
-            "note": "second of two calls; host-pointer path incl. copies; estimates vs generating rates differ by design (the "
-                    "simulation has Gamma site rates, stage 1 assumes one rate)",
+            "note": "second of two calls; tphip_stage1_fit through the pipeline: host-pointer path from pinned memory incl. the "
+                    "upload; estimates vs generating rates differ by design (the simulation has Gamma site rates, stage 1 "
+                    "assumes one rate)",
             "max_rel_dev_from_generating_rates": float(np.max(np.abs(exch - true / true[:, 1:2]) / (true / true[:, 1:2])))}
 
 

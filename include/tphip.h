@@ -147,6 +147,11 @@ int tphip_plan_op_counts(const tphip_plan *plan, int32_t *counts);
 int32_t tphip_plan_cherry_count(const tphip_plan *plan);
 /* copy the per-locus eigen-systems back (tests): lam[L*4], U[L*16], Uinv[L*16], kappa[L] */
 int tphip_plan_get_models(const tphip_plan *plan, double *lam, double *U, double *Uinv, double *kappa);
+/* Replace the per-locus models of an existing plan: pi [nloci*4] and / or exch [nloci*6] (host; NULL keeps the current
+ * values).  The eigen-systems are recomputed on the device.  What it is for: one plan per batch through both stages of
+ * HyPhy's script -- tphip_stage1_fit estimates the exchangeabilities (bf:405-897), the per-site loop then runs on them
+ * (bf:970-976) -- instead of a second plan.  Same validation as tphip_plan_create. */
+int tphip_plan_set_models(tphip_plan *plan, const double *pi, const double *exch);
 
 /* ------------------------------------------------------------------------------------------------
  * Device-pointer entry points (the hot path).  `stream` is a hipStream_t (NULL = default stream).
@@ -236,6 +241,7 @@ int tphip_locus_gradient_dev(tphip_plan *plan, const uint8_t *d_states, int64_t 
  * (AC, AG, AT, CG, CT, GT) in lexicographic order = the order of the loops at bf:544-566.
  * Outputs are HOST arrays (the call synchronises `stream` before it returns); all but exch may be NULL:
  *   exch[L][6]           model-averaged AC, AG (= 1), AT, CG, CT, GT -- what stage 2 takes (bf:838-847)
+ *   pi[L][4]             the base frequencies used (the plan's, or the empirical ones: opts.empirical_pi)
  *   weights[L][203]      Akaike weights;  lnl[L][203] maximised log-likelihoods;  model_exch[L][203][6] fitted rates
  *   grm_blen[L][nnodes]  branch lengths t_b of the general model (stash / totalFactor)
  *   grm_iters[L], sub_iters[L][202]  optimiser iterations;  stats[8] = likelihood evaluations, gradients, evaluations and
@@ -251,14 +257,24 @@ typedef struct tphip_stage1_opts {
     int32_t free_root_pair; /* 1 = the two branches below a bifurcating root are separate coordinates, as in HyPhy's
                                parameter list (default 0: one coordinate for their sum, which is all a reversible
                                model's likelihood depends on; the reported pair keeps the input tree's proportion)  */
+    int32_t compress_patterns; /* 1 = the plan's columns are raw alignment columns: collapse them on the device into unique
+                               site patterns with counts first, which is what HyPhy's likelihood function sums over
+                               (GetDataInfo(dupInfo...), bf:960-963).  0 = evaluate the plan's columns as they are (with
+                               the plan's column weights, if set)                                                    */
+    int32_t empirical_pi;   /* 1 = base frequencies from the alignment itself, HarvestFrequencies(.., 1, 1, 1) (bf:968):
+                               every cell adds 1 / popcount(mask) to each base it may be.  They replace the plan's pi
+                               (as tphip_plan_set_models would) and are returned in `pi`.  0 = the plan's pi          */
+    int64_t row_pitch;      /* host-pointer call only: bytes between taxon rows of `states` (0 = the plan's column count).
+                               Lets a caller pass a column range of a bigger taxon-major array without copying it.   */
 } tphip_stage1_opts;
 
-int tphip_stage1_fit_dev(tphip_plan *plan, const uint8_t *d_states, const tphip_stage1_opts *opts, double *exch,
+int tphip_stage1_fit_dev(tphip_plan *plan, const uint8_t *d_states, const tphip_stage1_opts *opts, double *exch, double *pi,
                          double *weights, double *lnl, double *model_exch, double *grm_blen, int32_t *grm_iters,
                          int32_t *sub_iters, int64_t *stats, void *stream);
-/* host-pointer twin: `states` is uploaded (and its state codes packed) once; d_states_cache as for tphip_locus_loglik */
+/* host-pointer twin: `states` is uploaded once (a 2-D copy when opts.row_pitch is set); d_states_cache as for
+ * tphip_locus_loglik (it must be NULL when row_pitch or compress_patterns is used: nothing of the upload is kept) */
 int tphip_stage1_fit(tphip_plan *plan, const uint8_t *states, void **d_states_cache, const tphip_stage1_opts *opts,
-                     double *exch, double *weights, double *lnl, double *model_exch, double *grm_blen,
+                     double *exch, double *pi, double *weights, double *lnl, double *model_exch, double *grm_blen,
                      int32_t *grm_iters, int32_t *sub_iters, int64_t *stats);
 
 /* Profiling hooks for bench.py: when enabled the library brackets its dominant kernel (site rates) with

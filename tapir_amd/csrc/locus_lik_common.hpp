@@ -6,7 +6,10 @@
 
 namespace tphip {
 
-constexpr int kLikBlock = 128;
+#ifndef TPHIP_LIK_BLOCK
+#define TPHIP_LIK_BLOCK 128   // threads per workgroup of the locus likelihood kernels (a build-time knob for A/B runs)
+#endif
+constexpr int kLikBlock = TPHIP_LIK_BLOCK;
 // A partial is rescaled when its largest entry falls below this.  Two partials meet in a POP_MUL before the next check,
 // so the threshold must keep the PRODUCT of two just-unscaled partials above the smallest normal number (1e-308):
 // 1e-200 let a 400-taxon tree underflow to L = 0.

@@ -121,8 +121,40 @@ unsigned blocks_for(int64_t n, int b) { return (unsigned)std::max<int64_t>(1, (n
 
 }  // namespace
 
+// The plan seen through other columns for the duration of a stage-1 call: the site patterns of its alignment instead of the
+// raw columns (opts.compress_patterns).  The likelihood entry points read these fields of the plan; the destructor puts the
+// plan's own back.
+struct PatternView {
+    tphip_plan* p = nullptr;
+    int64_t ncols = 0, max_locus_cols = 0;
+    int64_t* d_offsets = nullptr;
+    double* d_col_weight = nullptr;
+    const uint8_t* lib_states = nullptr;
+    uint32_t* d_value_packed = nullptr;
+    std::vector<int64_t> h_offsets;
+    uint8_t* d_pat = nullptr; int64_t* d_poff = nullptr; double* d_pw = nullptr; uint32_t* d_ppacked = nullptr;
+    void install(tphip_plan* plan, uint8_t* pat, int64_t* poff, double* pw, uint32_t* packed, int64_t npat, std::vector<int64_t>&& hoff) {
+        p = plan;
+        ncols = p->ncols; max_locus_cols = p->max_locus_cols; d_offsets = p->d_offsets.p; d_col_weight = p->d_col_weight;
+        lib_states = p->lib_states; d_value_packed = p->d_value_packed; h_offsets.swap(p->h_offsets);
+        d_pat = pat; d_poff = poff; d_pw = pw; d_ppacked = packed;
+        p->ncols = npat; p->d_offsets.p = poff; p->d_col_weight = pw; p->lib_states = packed ? pat : nullptr; p->d_value_packed = packed;
+        p->h_offsets = std::move(hoff);
+        p->max_locus_cols = 0;
+        for (size_t l = 0; l + 1 < p->h_offsets.size(); ++l)
+            p->max_locus_cols = std::max<int64_t>(p->max_locus_cols, p->h_offsets[l + 1] - p->h_offsets[l]);
+    }
+    ~PatternView() {
+        if (p) {
+            p->ncols = ncols; p->max_locus_cols = max_locus_cols; p->d_offsets.p = d_offsets; p->d_col_weight = d_col_weight;
+            p->lib_states = lib_states; p->d_value_packed = d_value_packed; p->h_offsets.swap(h_offsets);
+        }
+        for (void* q : {(void*)d_pat, (void*)d_poff, (void*)d_pw, (void*)d_ppacked}) if (q) (void)hipFree(q);
+    }
+};
+
 extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, const tphip_stage1_opts* opts_in, double* exch_out,
-                                    double* weights_out, double* lnl_out, double* model_exch_out, double* grm_blen_out,
+                                    double* pi_out, double* weights_out, double* lnl_out, double* model_exch_out, double* grm_blen_out,
                                     int32_t* grm_iters_out, int32_t* sub_iters_out, int64_t* stats_out, void* stream) {
     if (!p || !d_states || !exch_out) return fail(TPHIP_ERR_INVALID, "null argument");
     tphip_stage1_opts opt;
@@ -174,15 +206,6 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
     std::vector<int8_t> cls_all;
     std::vector<int32_t> kk_all;
     model_design(strings, &cls_all, &kk_all);
-    // per-locus constants: pi normalised, dk = 2 pi_i pi_j (totalFactor = exch . dk, bf:531-534)
-    static const int PI_[6] = {0, 0, 0, 1, 1, 2}, PJ_[6] = {1, 2, 3, 2, 3, 3};
-    std::vector<double> h_dk((size_t)L * 6);
-    for (int l = 0; l < L; ++l) {
-        double pi[4], s = 0;
-        for (int k = 0; k < 4; ++k) { pi[k] = desc->pi[(size_t)l * 4 + k]; s += pi[k]; }
-        for (int k = 0; k < 4; ++k) pi[k] /= s;
-        for (int q = 0; q < 6; ++q) h_dk[(size_t)l * 6 + q] = 2.0 * pi[PI_[q]] * pi[PJ_[q]];
-    }
     // start shape of the branch lengths: the input tree's lengths over their mean, floored
     std::vector<double> h_shape(nn, 0.0);
     {
@@ -204,7 +227,7 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
     struct Extra {
         int32_t* counters; int32_t *branches, *node_coord, *partner; double *dk, *shape, *grid, *node_w; int8_t* cls; int32_t* kk;
         double *grm_exch, *grm_blen, *stash, *grm_lnl; uint8_t* flags; int32_t* sub_iters; void* cub_tmp; int32_t* nsel;
-        double *o_weights, *o_lnl, *o_mexch, *o_exch;
+        double *o_weights, *o_lnl, *o_mexch, *o_exch, *pi; unsigned long long* hist;
     } X;
     size_t cub_bytes = 0;
     {
@@ -219,7 +242,7 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
         X.grm_exch = A.take<double>(P * 6); X.grm_blen = A.take<double>(P * nn); X.stash = A.take<double>(P * nn); X.grm_lnl = A.take<double>(P);
         X.flags = A.take<uint8_t>(LM); X.sub_iters = A.take<int32_t>(LM); X.cub_tmp = A.take<char>(cub_bytes); X.nsel = A.take<int32_t>(1);
         X.o_weights = A.take<double>(P * kModels); X.o_lnl = A.take<double>(P * kModels); X.o_mexch = A.take<double>(P * kModels * 6);
-        X.o_exch = A.take<double>(P * 6);
+        X.o_exch = A.take<double>(P * 6); X.pi = A.take<double>(P * 4); X.hist = A.take<unsigned long long>(P * 16);
         CandArrays C = take_cands(A, cap);
         // general model
         G.P = L; G.D = D; G.nb = nb; G.nn = nn; G.bspace_metric = getenv("TPHIP_S1_LOGMETRIC") ? 0 : 1; G.node_coord = X.node_coord; G.branches = X.branches; G.dk = X.dk;
@@ -274,12 +297,49 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
     HIP_TRY(hipMemcpyAsync(X.node_coord, node_coord.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.partner, partner.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.node_w, node_w.data(), sizeof(double) * nn, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(X.dk, h_dk.data(), sizeof(double) * P * 6, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.shape, h_shape.data(), sizeof(double) * nn, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.grid, h_grid.data(), sizeof(double) * ngrid, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.cls, h_cls.data(), sizeof(int8_t) * kSubModels * 6, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.kk, h_kk.data(), sizeof(int32_t) * kSubModels, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // the host vectors above go out of use
+
+    // ---- base frequencies and site patterns (bf:960-968) ---------------------------------------------------------------------
+    if (opt.empirical_pi) {
+        int rc = tphip_state_histogram_dev(p->device, d_states, p->ncols, p->ntaxa, p->d_offsets.p, L, (int64_t*)X.hist, (void*)st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(empirical_pi_kernel, dim3(blocks_for(L, 64)), dim3(64), 0, st, L, (const unsigned long long*)X.hist, X.pi);
+        KCHECK();
+        std::vector<double> ones((size_t)L * 6, 1.0);
+        HIP_TRY(hipMemcpyAsync(X.o_mexch, ones.data(), sizeof(double) * L * 6, hipMemcpyHostToDevice, st));   // (a free buffer)
+        RC(tphip_internal_set_models_dev(p, X.pi, X.o_mexch, (void*)st));
+        std::vector<double> hpi((size_t)L * 4);
+        HIP_TRY(hipMemcpyAsync(hpi.data(), X.pi, sizeof(double) * L * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        RC(tphip_internal_store_pi(p, hpi.data()));
+        desc = tphip_internal_saved_desc(p);
+    }
+    PatternView view;
+    if (opt.compress_patterns && p->ncols > 0) {
+        HIP_TRY(hipStreamSynchronize(st));
+        uint8_t* d_pat = nullptr; int64_t* d_poff = nullptr; double* d_pw = nullptr; int64_t npat = 0;
+        RC(tphip_internal_compress_dev(d_states, p->ncols, p->ntaxa, p->d_offsets.p, L, &d_pat, &d_poff, &d_pw, &npat));
+        std::vector<int64_t> hoff((size_t)L + 1);
+        uint32_t* d_packed = nullptr;
+        hipError_t e = hipMemcpy(hoff.data(), d_poff, sizeof(int64_t) * ((size_t)L + 1), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && p->value_cols > 0 && npat > 0) {
+            e = hipMalloc((void**)&d_packed, sizeof(uint32_t) * (size_t)p->nwords * (size_t)npat);
+            if (e == hipSuccess) e = launch_value_pack_codes_kernel(st, d_pat, npat, p->d_tip_taxon.p, p->nwords, d_packed);
+        }
+        if (e != hipSuccess) {
+            for (void* q : {(void*)d_pat, (void*)d_poff, (void*)d_pw, (void*)d_packed}) if (q) (void)hipFree(q);
+            return fail(TPHIP_ERR_HIP, std::string("site patterns: ") + hipGetErrorString(e));
+        }
+        view.install(p, d_pat, d_poff, d_pw, d_packed, npat, std::move(hoff));
+        d_states = d_pat;
+        dr.d_states = d_pat;
+    }
+    hipLaunchKernelGGL(dk_kernel, dim3(blocks_for(L, 64)), dim3(64), 0, st, L, p->d_models.p, X.dk);
+    KCHECK();
 
     // ---- general model ---------------------------------------------------------------------------------------------------------
     // start: tree shape times the best of a grid of scales (17 likelihoods per locus under the all-ones model)
@@ -459,6 +519,10 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
                        X.o_exch, weights_out ? X.o_weights : nullptr, lnl_out ? X.o_lnl : nullptr, model_exch_out ? X.o_mexch : nullptr);
     KCHECK();
     HIP_TRY(hipMemcpyAsync(exch_out, X.o_exch, sizeof(double) * P * 6, hipMemcpyDeviceToHost, st));
+    if (pi_out) {
+        if (opt.empirical_pi) HIP_TRY(hipMemcpyAsync(pi_out, X.pi, sizeof(double) * P * 4, hipMemcpyDeviceToHost, st));
+        else memcpy(pi_out, desc->pi, sizeof(double) * P * 4);
+    }
     if (weights_out) HIP_TRY(hipMemcpyAsync(weights_out, X.o_weights, sizeof(double) * P * kModels, hipMemcpyDeviceToHost, st));
     if (lnl_out) HIP_TRY(hipMemcpyAsync(lnl_out, X.o_lnl, sizeof(double) * P * kModels, hipMemcpyDeviceToHost, st));
     if (model_exch_out) HIP_TRY(hipMemcpyAsync(model_exch_out, X.o_mexch, sizeof(double) * P * kModels * 6, hipMemcpyDeviceToHost, st));
@@ -474,16 +538,40 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
 }
 
 extern "C" int tphip_stage1_fit(tphip_plan* p, const uint8_t* states, void** d_states_cache, const tphip_stage1_opts* opts,
-                                double* exch_out, double* weights_out, double* lnl_out, double* model_exch_out, double* grm_blen_out,
-                                int32_t* grm_iters_out, int32_t* sub_iters_out, int64_t* stats_out) {
+                                double* exch_out, double* pi_out, double* weights_out, double* lnl_out, double* model_exch_out,
+                                double* grm_blen_out, int32_t* grm_iters_out, int32_t* sub_iters_out, int64_t* stats_out) {
     if (!p || !states) return fail(TPHIP_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(p->device));
+    tphip_stage1_opts opt;
+    memset(&opt, 0, sizeof(opt));
+    if (opts) {
+        if (opts->struct_size < sizeof(uint32_t) || opts->struct_size > 4096)
+            return fail(TPHIP_ERR_INVALID, "tphip_stage1_opts.struct_size not set");
+        memcpy(&opt, opts, std::min<size_t>(opts->struct_size, sizeof(opt)));
+    }
+    const size_t n = (size_t)p->ncols, pitch = opt.row_pitch > 0 ? (size_t)opt.row_pitch : n;
+    if (pitch < n) return fail(TPHIP_ERR_INVALID, "row_pitch smaller than the plan's column count");
+    if (pitch != n || opt.compress_patterns) {
+        // nothing of this upload is worth keeping: a column range of a bigger array, or columns that are collapsed into
+        // patterns right away
+        if (d_states_cache) return fail(TPHIP_ERR_INVALID, "d_states_cache must be NULL with row_pitch / compress_patterns");
+        uint8_t* d_s = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_s, n * (size_t)p->ntaxa + 1));
+        hipError_t e = pitch == n ? hipMemcpy(d_s, states, n * (size_t)p->ntaxa, hipMemcpyHostToDevice)
+                                  : hipMemcpy2D(d_s, n, states, pitch, n, (size_t)p->ntaxa, hipMemcpyHostToDevice);
+        int rc = e == hipSuccess ? TPHIP_OK : fail(TPHIP_ERR_HIP, std::string("upload of the alignment: ") + hipGetErrorString(e));
+        if (!rc)
+            rc = tphip_stage1_fit_dev(p, d_s, &opt, exch_out, pi_out, weights_out, lnl_out, model_exch_out, grm_blen_out, grm_iters_out,
+                                      sub_iters_out, stats_out, nullptr);
+        (void)hipFree(d_s);
+        return rc;
+    }
     void* local = nullptr;
     void** cache = d_states_cache ? d_states_cache : &local;
     uint8_t* d_s = nullptr;
     int rc = tphip_internal_stage_alignment(p, states, cache, &d_s);
     if (!rc)
-        rc = tphip_stage1_fit_dev(p, d_s, opts, exch_out, weights_out, lnl_out, model_exch_out, grm_blen_out, grm_iters_out,
+        rc = tphip_stage1_fit_dev(p, d_s, &opt, exch_out, pi_out, weights_out, lnl_out, model_exch_out, grm_blen_out, grm_iters_out,
                                   sub_iters_out, stats_out, nullptr);
     if (!d_states_cache && local) {
         const int rf = tphip_free_device(p, local);

@@ -17,6 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include "gtr_model.hpp"
 
 namespace tphip {
 namespace s1 {
@@ -382,6 +383,32 @@ __global__ __launch_bounds__(64) void grm_update_kernel(GrmState G) {
         G.iters[p] += 1;
         G.phase[p] = PH_LIVE;
     }
+}
+
+// HarvestFrequencies(Freqs, filter, 1, 1, 1) (bf:968) from the per-locus histogram of state masks: every cell adds
+// 1 / popcount(mask) to each base it may be (a gap counts 1/4 to each); a locus without cells gets 1/4 each.  The floor
+// keeps a base that never occurs from making the eigen-form singular (as at plan creation).  thread = locus
+__global__ __launch_bounds__(64) void empirical_pi_kernel(int32_t L, const unsigned long long* hist, double* pi_out) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    double c[4] = {0, 0, 0, 0};
+    for (int m = 0; m < 16; ++m) {
+        const double n = (double)hist[(size_t)l * 16 + m];
+        const int mm = m ? m : 15;
+        const double w = n / (double)__popc(mm);
+        for (int k = 0; k < 4; ++k) if ((mm >> k) & 1) c[k] += w;
+    }
+    const double tot = c[0] + c[1] + c[2] + c[3];
+    for (int k = 0; k < 4; ++k) pi_out[(size_t)l * 4 + k] = tot > 0 ? fmax(c[k] / tot, 1e-12) : 0.25;
+}
+
+// dk[l][q] = 2 pi_i pi_j over the rate pairs (AC, AG, AT, CG, CT, GT): totalFactor(r) = r . dk (bf:531-534); thread = locus
+__global__ __launch_bounds__(64) void dk_kernel(int32_t L, const LocusModel* models, double* dk) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const double* pi = models[l].pi;
+    const int PI_[6] = {0, 0, 0, 1, 1, 2}, PJ_[6] = {1, 2, 3, 2, 3, 3};
+    for (int q = 0; q < 6; ++q) dk[(size_t)l * 6 + q] = 2.0 * pi[PI_[q]] * pi[PJ_[q]];
 }
 
 // start of the branch lengths: the input tree's shape rescaled to the best of a grid of scales under the all-ones model

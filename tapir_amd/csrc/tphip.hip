@@ -1266,6 +1266,69 @@ int tphip_plan_set_column_weights(tphip_plan* p, const double* weights) {
     return TPHIP_OK;
 }
 
+// per-locus eigen-systems from DEVICE arrays pi [L][4] (floored, any scale) and exch [L][6]; for stage1_driver.hip
+int tphip_internal_set_models_dev(tphip_plan* p, const double* d_pi, const double* d_exch, void* stream) {
+    const int bs = 64;
+    gtr_setup_kernel<<<dim3((unsigned)((p->nloci + bs - 1) / bs)), dim3(bs), 0, (hipStream_t)stream>>>(d_pi, d_exch, p->nloci, p->d_models.p);
+    HIP_TRY(hipGetLastError());
+    return TPHIP_OK;
+}
+
+// the plan's record of its base frequencies after they were replaced on the device (stage1_driver.hip: empirical_pi)
+int tphip_internal_store_pi(tphip_plan* p, const double* pi) {
+    if (!p || !p->saved) return fail(TPHIP_ERR_INVALID, "plan has no saved descriptor");
+    p->saved->pi.assign(pi, pi + 4 * (size_t)p->nloci);
+    p->saved->d.pi = p->saved->pi.data();
+    for (tphip_plan* q : p->parts) (void)tphip_plan_destroy(q);
+    p->parts.clear();
+    return TPHIP_OK;
+}
+
+int tphip_plan_set_models(tphip_plan* p, const double* pi, const double* exch) {
+    if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    if (!p->saved) return fail(TPHIP_ERR_INVALID, "plan has no saved descriptor");
+    const size_t L = (size_t)p->nloci;
+    if (pi) {
+        for (size_t l = 0; l < L; ++l) {
+            int npos = 0;
+            for (int k = 0; k < 4; ++k) {
+                if (!(pi[l * 4 + k] >= 0.0) || !std::isfinite(pi[l * 4 + k]))
+                    return fail(TPHIP_ERR_INVALID, "base frequencies of locus " + std::to_string(l) + " must be finite and >= 0");
+                npos += pi[l * 4 + k] > 0.0;
+            }
+            if (npos < 2) return fail(TPHIP_ERR_INVALID, "locus " + std::to_string(l) + " has fewer than two bases with a positive frequency");
+        }
+        p->saved->pi.assign(pi, pi + 4 * L);
+    }
+    if (exch) {
+        for (size_t i = 0; i < 6 * L; ++i)
+            if (!(exch[i] >= 0.0)) return fail(TPHIP_ERR_INVALID, "exchangeabilities must be >= 0");
+        p->saved->exch.assign(exch, exch + 6 * L);
+    }
+    p->saved->d.pi = p->saved->pi.data();
+    p->saved->d.exch = p->saved->exch.data();
+    HIP_TRY(hipSetDevice(p->device));
+    std::vector<double> hpi(p->saved->pi);
+    for (size_t l = 0; l < L; ++l) {   // same floor as at plan creation
+        double sum = 0;
+        for (int k = 0; k < 4; ++k) sum += hpi[4 * l + k];
+        for (int k = 0; k < 4; ++k) hpi[4 * l + k] = std::max(hpi[4 * l + k], kPiFloor * sum);
+    }
+    Scratch S;
+    double* d_pi = S.get<double>(4 * L);
+    double* d_ex = S.get<double>(6 * L);
+    if (!d_pi || !d_ex) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemcpy(d_pi, hpi.data(), sizeof(double) * 4 * L, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_ex, p->saved->exch.data(), sizeof(double) * 6 * L, hipMemcpyHostToDevice));
+    int rc = tphip_internal_set_models_dev(p, d_pi, d_ex, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    // locus groups of the pipelined host path were built from the old models: rebuilt on next use
+    for (tphip_plan* q : p->parts) (void)tphip_plan_destroy(q);
+    p->parts.clear();
+    return TPHIP_OK;
+}
+
 int tphip_free_device(tphip_plan* p, void* d_ptr) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
     HIP_TRY(hipSetDevice(p->device));
@@ -1443,6 +1506,68 @@ int tphip_locus_gradient(tphip_plan* p, const uint8_t* states, void** d_states_c
     return TPHIP_OK;
 }
 
+// Unique site patterns of device-resident columns (see tphip_compress_columns): temporaries in `tmp`, results in `keep`.
+static int compress_core(const uint8_t* d_s, int64_t ncols_total, int32_t ntaxa, const int64_t* d_off, int64_t nloci, bool want_map,
+                         Scratch& tmp, Scratch& keep, uint8_t** d_out_p, int64_t** d_newoff_p, double** d_w_p, int64_t** d_map_p,
+                         int64_t* npat_p) {
+    const size_t n = (size_t)ncols_total;
+    const int32_t nwords = (ntaxa + 7) / 8;
+    uint32_t* d_packed = tmp.get<uint32_t>(n * (size_t)nwords);
+    uint64_t* d_key = tmp.get<uint64_t>(n);
+    uint64_t* d_key2 = tmp.get<uint64_t>(n);
+    uint64_t* d_h2 = tmp.get<uint64_t>(n);
+    uint32_t* d_col = tmp.get<uint32_t>(n);
+    uint32_t* d_col2 = tmp.get<uint32_t>(n);
+    int32_t* d_head = tmp.get<int32_t>(n);
+    int64_t* d_incl = tmp.get<int64_t>(n);
+    int64_t* d_newoff = keep.get<int64_t>((size_t)nloci + 1);
+    int64_t* d_map = want_map ? keep.get<int64_t>(n) : nullptr;
+    if (!d_packed || !d_key || !d_key2 || !d_h2 || !d_col || !d_col2 || !d_head || !d_incl || !d_newoff || (want_map && !d_map))
+        return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    pack_hash_kernel<<<dim3(blocks), dim3(256)>>>(d_s, ncols_total, ntaxa, nwords, d_off, nloci, d_packed, d_key, d_h2, d_col);
+    HIP_TRY(hipGetLastError());
+    int locus_bits = 1;
+    while (((int64_t)1 << locus_bits) < nloci) ++locus_bits;
+    const int end_bit = std::min(64, kPatHashBits + locus_bits);
+    size_t tmp_sort = 0, tmp_scan = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, d_key, d_key2, d_col, d_col2, (int)n, 0, end_bit));
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, d_head, d_incl, (int)n));
+    void* d_tmp = tmp.get<char>(std::max(tmp_sort, tmp_scan));
+    if (!d_tmp) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_sort, d_key, d_key2, d_col, d_col2, (int)n, 0, end_bit));
+    head_flag_kernel<<<dim3(blocks), dim3(256)>>>(d_key2, d_col2, d_h2, d_packed, nwords, ncols_total, d_head);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tmp_scan, d_head, d_incl, (int)n));
+    int64_t npat = 0;
+    HIP_TRY(hipMemcpy(&npat, d_incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
+    uint8_t* d_out = keep.get<uint8_t>((size_t)npat * (size_t)ntaxa);
+    int32_t* d_count = tmp.get<int32_t>((size_t)npat);
+    double* d_w = keep.get<double>((size_t)npat);
+    if (!d_out || !d_count || !d_w) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    HIP_TRY(hipMemset(d_count, 0, sizeof(int32_t) * (size_t)npat));
+    pattern_scatter_kernel<<<dim3(blocks), dim3(256)>>>(d_col2, d_head, d_incl, d_packed, nwords, ntaxa, ncols_total, npat, d_out,
+                                                      d_count, d_map);
+    pattern_offsets_kernel<<<dim3((unsigned)((nloci + 256) / 256)), dim3(256)>>>(d_off, nloci, ncols_total, d_incl, npat, d_newoff);
+    count_to_weight_kernel<<<dim3((unsigned)((npat + 255) / 256)), dim3(256)>>>(d_count, npat, d_w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    *d_out_p = d_out; *d_newoff_p = d_newoff; *d_w_p = d_w; *npat_p = npat;
+    if (d_map_p) *d_map_p = d_map;
+    return TPHIP_OK;
+}
+
+// device-to-device twin for the other translation units (stage1_driver.hip); the three result arrays are the caller's to hipFree
+int tphip_internal_compress_dev(const uint8_t* d_s, int64_t ncols_total, int32_t ntaxa, const int64_t* d_off, int64_t nloci,
+                                uint8_t** d_out, int64_t** d_newoff, double** d_w, int64_t* npat) {
+    if (ncols_total >= ((int64_t)1 << 31)) return fail(TPHIP_ERR_INVALID, "too many columns for one call (2^31)");
+    if (nloci >= ((int64_t)1 << (64 - kPatHashBits))) return fail(TPHIP_ERR_INVALID, "too many loci for one call");
+    Scratch tmp, keep;
+    int rc = compress_core(d_s, ncols_total, ntaxa, d_off, nloci, false, tmp, keep, d_out, d_newoff, d_w, nullptr, npat);
+    if (!rc) keep.bufs.clear();   // ownership passes to the caller
+    return rc;
+}
+
 int tphip_compress_columns(int32_t device, const uint8_t* states, int64_t ncols_total, int32_t ntaxa,
                            const int64_t* locus_offsets, int64_t nloci, uint8_t* out_states, int64_t* out_offsets,
                            double* out_weight, int64_t* out_map, int64_t* out_npatterns) {
@@ -1461,54 +1586,16 @@ int tphip_compress_columns(int32_t device, const uint8_t* states, int64_t ncols_
         return TPHIP_OK;
     }
     HIP_TRY(hipSetDevice(device));
-    Scratch S;
+    Scratch S, K;
     const size_t n = (size_t)ncols_total;
-    const int32_t nwords = (ntaxa + 7) / 8;
     uint8_t* d_s = S.get<uint8_t>(n * (size_t)ntaxa);
     int64_t* d_off = S.get<int64_t>((size_t)nloci + 1);
-    uint32_t* d_packed = S.get<uint32_t>(n * (size_t)nwords);
-    uint64_t* d_key = S.get<uint64_t>(n);
-    uint64_t* d_key2 = S.get<uint64_t>(n);
-    uint64_t* d_h2 = S.get<uint64_t>(n);
-    uint32_t* d_col = S.get<uint32_t>(n);
-    uint32_t* d_col2 = S.get<uint32_t>(n);
-    int32_t* d_head = S.get<int32_t>(n);
-    int64_t* d_incl = S.get<int64_t>(n);
-    int64_t* d_newoff = S.get<int64_t>((size_t)nloci + 1);
-    int64_t* d_map = out_map ? S.get<int64_t>(n) : nullptr;
-    if (!d_s || !d_off || !d_packed || !d_key || !d_key2 || !d_h2 || !d_col || !d_col2 || !d_head || !d_incl || !d_newoff ||
-        (out_map && !d_map))
-        return fail(TPHIP_ERR_HIP, "hipMalloc failed");
+    if (!d_s || !d_off) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
     HIP_TRY(hipMemcpy(d_s, states, n * (size_t)ntaxa, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_off, locus_offsets, sizeof(int64_t) * ((size_t)nloci + 1), hipMemcpyHostToDevice));
-    const unsigned blocks = (unsigned)((n + 255) / 256);
-    pack_hash_kernel<<<dim3(blocks), dim3(256)>>>(d_s, ncols_total, ntaxa, nwords, d_off, nloci, d_packed, d_key, d_h2, d_col);
-    HIP_TRY(hipGetLastError());
-    int locus_bits = 1;
-    while (((int64_t)1 << locus_bits) < nloci) ++locus_bits;
-    const int end_bit = std::min(64, kPatHashBits + locus_bits);
-    size_t tmp_sort = 0, tmp_scan = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, d_key, d_key2, d_col, d_col2, (int)n, 0, end_bit));
-    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, d_head, d_incl, (int)n));
-    void* d_tmp = S.get<char>(std::max(tmp_sort, tmp_scan));
-    if (!d_tmp) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_sort, d_key, d_key2, d_col, d_col2, (int)n, 0, end_bit));
-    head_flag_kernel<<<dim3(blocks), dim3(256)>>>(d_key2, d_col2, d_h2, d_packed, nwords, ncols_total, d_head);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipcub::DeviceScan::InclusiveSum(d_tmp, tmp_scan, d_head, d_incl, (int)n));
-    int64_t npat = 0;
-    HIP_TRY(hipMemcpy(&npat, d_incl + (n - 1), sizeof(int64_t), hipMemcpyDeviceToHost));
-    uint8_t* d_out = S.get<uint8_t>((size_t)npat * (size_t)ntaxa);
-    int32_t* d_count = S.get<int32_t>((size_t)npat);
-    double* d_w = S.get<double>((size_t)npat);
-    if (!d_out || !d_count || !d_w) return fail(TPHIP_ERR_HIP, "hipMalloc failed");
-    HIP_TRY(hipMemset(d_count, 0, sizeof(int32_t) * (size_t)npat));
-    pattern_scatter_kernel<<<dim3(blocks), dim3(256)>>>(d_col2, d_head, d_incl, d_packed, nwords, ntaxa, ncols_total, npat, d_out,
-                                                      d_count, d_map);
-    pattern_offsets_kernel<<<dim3((unsigned)((nloci + 256) / 256)), dim3(256)>>>(d_off, nloci, ncols_total, d_incl, npat, d_newoff);
-    count_to_weight_kernel<<<dim3((unsigned)((npat + 255) / 256)), dim3(256)>>>(d_count, npat, d_w);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    uint8_t* d_out = nullptr; int64_t* d_newoff = nullptr; double* d_w = nullptr; int64_t* d_map = nullptr; int64_t npat = 0;
+    int rc = compress_core(d_s, ncols_total, ntaxa, d_off, nloci, out_map != nullptr, S, K, &d_out, &d_newoff, &d_w, &d_map, &npat);
+    if (rc) return rc;
     HIP_TRY(hipMemcpy(out_states, d_out, (size_t)npat * (size_t)ntaxa, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_offsets, d_newoff, sizeof(int64_t) * ((size_t)nloci + 1), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out_weight, d_w, sizeof(double) * (size_t)npat, hipMemcpyDeviceToHost));

@@ -157,4 +157,10 @@ extern "C" {
 __attribute__((visibility("hidden"))) int tphip_internal_stage_alignment(tphip_plan* p, const uint8_t* states, void** d_states_cache,
                                                                        uint8_t** d_s);
 __attribute__((visibility("hidden"))) const tphip_plan_desc* tphip_internal_saved_desc(const tphip_plan* p);
+__attribute__((visibility("hidden"))) int tphip_internal_compress_dev(const uint8_t* d_s, int64_t ncols_total, int32_t ntaxa,
+                                                                    const int64_t* d_off, int64_t nloci, uint8_t** d_out,
+                                                                    int64_t** d_newoff, double** d_w, int64_t* npat);
+__attribute__((visibility("hidden"))) int tphip_internal_store_pi(tphip_plan* p, const double* pi);
+__attribute__((visibility("hidden"))) int tphip_internal_set_models_dev(tphip_plan* p, const double* d_pi, const double* d_exch,
+                                                                      void* stream);
 }

@@ -38,7 +38,8 @@ class PlanDesc(ctypes.Structure):
 
 class Stage1Opts(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("maxit_grm", _i32), ("maxit_sub", _i32), ("no_prune", _i32),
-                ("fd_step", _f64), ("free_root_pair", _i32)]
+                ("fd_step", _f64), ("free_root_pair", _i32), ("compress_patterns", _i32), ("empirical_pi", _i32),
+                ("row_pitch", _i64)]
 
 
 # every symbol include/tphip.h declares: (name, restype, argtypes)
@@ -84,8 +85,9 @@ SYMBOLS = [
     ("tphip_compress_columns", ctypes.c_int, [ctypes.c_int32, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     ("tphip_locus_gradient", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), _i64, _vp, _i64] + [_vp] * 11),
     ("tphip_free_device", ctypes.c_int, [_vp, _vp]),
-    ("tphip_stage1_fit_dev", ctypes.c_int, [_vp, _vp, ctypes.POINTER(Stage1Opts)] + [_vp] * 9),
-    ("tphip_stage1_fit", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(Stage1Opts)] + [_vp] * 8),
+    ("tphip_stage1_fit_dev", ctypes.c_int, [_vp, _vp, ctypes.POINTER(Stage1Opts)] + [_vp] * 10),
+    ("tphip_stage1_fit", ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(Stage1Opts)] + [_vp] * 9),
+    ("tphip_plan_set_models", ctypes.c_int, [_vp, _vp, _vp]),
 ]
 
 _lib = None
@@ -381,17 +383,25 @@ class Plan:
         return (lnl, dex, dlt, st, d2) if curvature else (lnl, dex, dlt, st)
 
     def stage1_fit(self, states, cache=None, details=True, maxit_grm=0, maxit_sub=0, prune_models=True, fd_step=0.0,
-                   free_root_pair=False):
+                   free_root_pair=False, compress_patterns=False, empirical_pi=False):
         """HyPhy's stage 1 for every locus of the plan in one engine call (tphip_stage1_fit): model-averaged
-        exchangeabilities [L, 6] and, with details, weights / lnl [L, 203], model_exch [L, 203, 6], grm_blen [L, nnodes],
-        iteration counts and counters.  The optimisers run on the device (csrc/stage1_opt_kernels.hpp)."""
-        states = _np(states, np.uint8)
+        exchangeabilities [L, 6], the base frequencies used [L, 4] and, with details, weights / lnl [L, 203], model_exch
+        [L, 203, 6], grm_blen [L, nnodes], iteration counts and counters.  The optimisers run on the device
+        (csrc/stage1_opt_kernels.hpp).  `states` may be a column range of a bigger C-contiguous [ntaxa, N] array (a view
+        states[:, a:b]): it is uploaded with one 2-D copy, not copied on the host.  compress_patterns: collapse the columns
+        into site patterns with counts on the device first (HyPhy's dupInfo); empirical_pi: HarvestFrequencies on the device."""
+        if states.dtype != np.uint8 or states.ndim != 2 or states.strides[1] != 1:
+            states = _np(states, np.uint8)
         assert states.shape == (self.ntaxa, self.ncols), (states.shape, self.ntaxa, self.ncols)
+        pitch = int(states.strides[0]) if self.ntaxa > 1 else self.ncols
+        if pitch != self.ncols and cache is not None:
+            raise ValueError("a device cache cannot hold a column range of a bigger array")
         L, nn = self.nloci, len(self._keep["parent"])
         opts = Stage1Opts(struct_size=ctypes.sizeof(Stage1Opts), maxit_grm=int(maxit_grm), maxit_sub=int(maxit_sub),
                           no_prune=0 if prune_models else 1, fd_step=float(fd_step),
-                          free_root_pair=1 if free_root_pair else 0)
-        out = dict(exch=np.empty((L, 6)))
+                          free_root_pair=1 if free_root_pair else 0, compress_patterns=1 if compress_patterns else 0,
+                          empirical_pi=1 if empirical_pi else 0, row_pitch=0 if pitch == self.ncols else pitch)
+        out = dict(exch=np.empty((L, 6)), pi=np.empty((L, 4)))
         if details:
             out.update(weights=np.empty((L, 203)), lnl=np.empty((L, 203)), model_exch=np.empty((L, 203, 6)),
                        grm_blen=np.empty((L, nn)), grm_iters=np.empty(L, np.int32), sub_iters=np.empty((L, 202), np.int32))
@@ -399,11 +409,19 @@ class Plan:
         ref = ctypes.byref(cache.ptr) if cache is not None else None
         g = lambda k: out[k].ctypes.data if k in out else None  # noqa: E731
         _check(self._lib.tphip_stage1_fit(self._h, states.ctypes.data, ref, ctypes.byref(opts), out["exch"].ctypes.data,
-                                          g("weights"), g("lnl"), g("model_exch"), g("grm_blen"), g("grm_iters"),
-                                          g("sub_iters"), stats.ctypes.data))
+                                          out["pi"].ctypes.data, g("weights"), g("lnl"), g("model_exch"), g("grm_blen"),
+                                          g("grm_iters"), g("sub_iters"), stats.ctypes.data))
         out["stats"] = dict(zip(("nevals", "ngrads", "grm_evals", "grm_grads", "pruned", "fitted", "grm_outer_iterations",
                                  "sub_outer_iterations"), stats.tolist()))
         return out
+
+    def set_models(self, pi=None, exch=None):
+        """Replace the per-locus base frequencies [L, 4] and / or exchangeabilities [L, 6] of the plan (tphip_plan_set_models)."""
+        a = None if pi is None else _np(pi, np.float64).reshape(-1)
+        b = None if exch is None else _np(exch, np.float64).reshape(-1)
+        if (a is not None and a.size != 4 * self.nloci) or (b is not None and b.size != 6 * self.nloci):
+            raise TphipError("pi must be [L,4] and exch [L,6]")
+        _check(self._lib.tphip_plan_set_models(self._h, _ptr(a), _ptr(b)))
 
     def set_column_weights(self, weights):
         """Column multiplicities for locus_loglik / locus_gradient (site-pattern counts); None removes them."""

@@ -295,28 +295,48 @@ def _shared_dir(need_bytes=0):
     return d
 
 
-STAGE1_BLOCK_LOCI = 8192   # loci fitted together (bounds memory: 8192 x 202 models x 9-point stencils = 15 M candidates at most).
-                           # An optimiser iteration costs a fixed ~7 ms of small launches whatever the block holds, and a block runs
-                           # until its slowest locus has converged: 8192 loci x 1000 x 64 taxa take 6.4-7.1 s in blocks of 2048,
-                           # 5.4 s in blocks of 4096, 4.5-4.9 s in one block
+STAGE1_BLOCK_LOCI = 16384  # loci fitted together by one tphip_stage1_fit call.  Bounds device memory (per locus ~0.5 MB of optimiser
+                           # state and candidate arrays: 202 models x 9-point stencils) and nothing else: the optimisers' fixed cost per
+                           # iteration is amortised over the block, and a block runs until its slowest locus has converged.
 
 
 def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, blen, leaf, T, times, intervals,
-                                     correction, device=0, block_loci=None):
+                                     correction, device=0, block_loci=None, return_pi=False):
     """Stage 1 of models_and_rates.bf (bf:405-897) for every locus -> [L, 6] AC, AG(=1), AT, CG, CT, GT.
-    Loci are independent, so they are fitted in blocks of `block_loci`: that bounds the optimiser's host memory and the
-    candidate batches (tens of thousands of loci would otherwise mean 10^7 candidates per likelihood call)."""
+
+    pi: [L, 4] base frequencies, or None = the empirical ones of each locus (HarvestFrequencies, bf:968), computed on the device
+    from the same upload.  With return_pi the frequencies used come back as a second array.
+    Loci are independent, so they are fitted in blocks of `block_loci` (bounds the optimiser's device memory).  With the
+    real engine a block is ONE call: its column range of `states` goes up with a 2-D copy (no host copy; pinned `states` =
+    direct DMA), the columns are collapsed into site patterns with counts on the device -- what HyPhy's likelihood function
+    sums over (bf:960-963) -- and the 203 fits and the averaging run there (csrc/stage1_driver.hip)."""
     from . import stage1
     offsets = np.asarray(offsets, dtype=np.int64)
-    pi = np.asarray(pi, dtype=np.float64).reshape(-1, 4)
     L = len(offsets) - 1
     step = int(block_loci or STAGE1_BLOCK_LOCI)
     out = np.empty((L, 6))
+    pi_used = np.empty((L, 4))
+    if pi is not None:
+        pi = np.asarray(pi, dtype=np.float64).reshape(-1, 4)
+    in_engine = hasattr(eng, "Plan") and hasattr(eng.Plan, "stage1_fit")
+    if pi is None and not in_engine:
+        pi = nexus.base_frequencies_from_histogram(eng.state_histogram(states, offsets, device=device))
     for l0 in range(0, L, step):
         l1 = min(L, l0 + step)
-        sub = np.ascontiguousarray(states[:, offsets[l0]:offsets[l1]])
         off = offsets[l0:l1 + 1] - offsets[l0]
-        # unique site patterns with counts, as HyPhy evaluates them (bf:960-963): every likelihood below runs on those
+        if in_engine:
+            cols = states[:, offsets[l0]:offsets[l1]]          # a view: rows are `states.strides[0]` bytes apart
+            blk_pi = np.full((l1 - l0, 4), 0.25) if pi is None else pi[l0:l1]
+            plan = eng.Plan(ntaxa, parent, blen, leaf, off, blk_pi, np.ones((l1 - l0, 6)), T, times, intervals,
+                            correction=correction, device=device)
+            try:
+                res = plan.stage1_fit(cols, details=False, compress_patterns=True, empirical_pi=pi is None)
+            finally:
+                plan.close()
+            out[l0:l1], pi_used[l0:l1] = res["exch"], res["pi"]
+            continue
+        # an engine without the call (the tests' CPU stand-in): site patterns, then the host optimiser of stage1.py
+        sub = np.ascontiguousarray(states[:, offsets[l0]:offsets[l1]])
         pstates, poffsets, weights, _ = eng.compress_columns(sub, off, device=device, want_map=False)
         plan = eng.Plan(ntaxa, parent, blen, leaf, poffsets, pi[l0:l1], np.ones((l1 - l0, 6)), T, times, intervals,
                         correction=correction, device=device)
@@ -324,9 +344,10 @@ def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, bl
             plan.set_column_weights(weights)
             out[l0:l1] = stage1.model_averaged_exchangeabilities(plan, pstates, pi[l0:l1], parent,
                                                                  np.asarray(blen) / correction)["exch"]
+            pi_used[l0:l1] = pi[l0:l1]
         finally:
             plan.close()
-    return out
+    return (out, pi_used) if return_pi else out
 
 
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
@@ -361,15 +382,15 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     states, offsets = load_alignments(alignments, leaf_names, pool, alloc=pinned)
     lap("parse_nexus")
     L = len(alignments)
-    if pi is None:
+    if pi is None and exch is not None:
         hist = eng.state_histogram(states, offsets, device=device)
         pi = nexus.base_frequencies_from_histogram(hist)
-    pi = np.asarray(pi, dtype=np.float64).reshape(L, 4)
     lap("base_frequencies")
-    if exch is None:
-        exch = model_averaged_exchangeabilities(eng, states, offsets, pi, len(leaf_names), parent, blen, leaf, T, times,
-                                                intervals, correction, device)
+    if exch is None:   # HyPhy's stage 1; the empirical base frequencies (when none are given) come from the same upload
+        exch, pi = model_averaged_exchangeabilities(eng, states, offsets, pi, len(leaf_names), parent, blen, leaf, T, times,
+                                                    intervals, correction, device, return_pi=True)
         lap("stage1_model_averaging")
+    pi = np.asarray(pi, dtype=np.float64).reshape(L, 4)
     exch = np.asarray(exch, dtype=np.float64)
     if exch.ndim == 1:
         exch = np.tile(exch, (L, 1))

@@ -186,6 +186,62 @@ def test_stage1_engine_matches_host_optimiser():
             assert np.allclose(a["grm_blen"][:, rk].sum(1), a2["grm_blen"][:, rk].sum(1), rtol=5e-3, atol=1e-9)
 
 
+def test_stage1_patterns_and_frequencies_on_the_device():
+    """tphip_stage1_fit with compress_patterns / empirical_pi / a column range of a bigger array (row_pitch) against the
+    same steps done by the caller: tphip_compress_columns + column weights, HarvestFrequencies from tphip_state_histogram,
+    a contiguous copy.  Site patterns with counts are the same likelihood as the raw columns (1e-8 of lnL: the order of the
+    column sum differs), so the estimates agree within the optimiser's reproducibility; tphip_plan_set_models then makes the
+    same plan run the per-site loop on them."""
+    engine = _engine()
+    from tapir_amd import nexus, synth
+    L, n, nt = 6, 400, 9
+    d = synth.simulate(L + 2, n, nt, 17)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    big = d["states"].numpy()                       # [nt, (L + 2) * n]: the middle L loci are the batch
+    rng = np.random.default_rng(3)
+    big[:, n:n + 150] = big[:, n + 150:n + 300]     # repeated columns: patterns with counts > 1
+    big[rng.integers(0, nt, 40), rng.integers(n, (L + 1) * n, 40)] = 15
+    view = big[:, n:(L + 1) * n]
+    sub = np.ascontiguousarray(view)
+    off = np.arange(L + 1, dtype=np.int64) * n
+    pi = nexus.base_frequencies_from_histogram(engine.state_histogram(sub, off))
+
+    def plan_for(offsets, p):
+        return engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], offsets, p, np.ones((L, 6)), pin["T"], [10], [[5, 15]],
+                           correction=pin["correction"])
+    # the caller does the steps
+    pst, poff, w, _ = engine.compress_columns(sub, off, want_map=False)
+    assert pst.shape[1] < sub.shape[1]
+    ref_plan = plan_for(poff, pi)
+    ref_plan.set_column_weights(w)
+    ref = ref_plan.stage1_fit(pst)
+    ref_plan.close()
+    # the engine does them, from the strided view, starting from placeholder frequencies
+    plan = plan_for(off, np.full((L, 4), 0.25))
+    got = plan.stage1_fit(view, compress_patterns=True, empirical_pi=True)
+    assert np.max(np.abs(got["pi"] - pi)) < 1e-14
+    assert np.max(np.abs(got["lnl"][:, 0] - ref["lnl"][:, 0]) / np.abs(ref["lnl"][:, 0])) < 1e-8
+    assert np.max(np.abs(got["exch"] - ref["exch"]) / ref["exch"]) < 1e-4
+    assert np.max(np.abs(got["weights"] - ref["weights"])) < 1e-4
+    raw = plan.stage1_fit(sub)                      # raw columns, no patterns: the same likelihood column by column
+    assert np.max(np.abs(raw["lnl"][:, 0] - ref["lnl"][:, 0]) / np.abs(ref["lnl"][:, 0])) < 1e-8
+    assert np.max(np.abs(raw["exch"] - ref["exch"]) / ref["exch"]) < 1e-4
+    # the same plan goes on to the per-site loop with the estimates
+    plan.set_models(exch=got["exch"])
+    out = plan.run_fused(sub)
+    plan.close()
+    fresh = plan_for(off, pi)
+    fresh.set_models(pi=pi, exch=got["exch"])
+    want = fresh.run_fused(sub)
+    fresh.close()
+    direct = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], off, pi, got["exch"], pin["T"], [10], [[5, 15]],
+                         correction=pin["correction"])
+    base = direct.run_fused(sub)
+    direct.close()
+    for k in ("rate", "lnl", "flag", "nres", "tables"):
+        assert np.array_equal(out[k], want[k], equal_nan=True) and np.array_equal(out[k], base[k], equal_nan=True), k
+
+
 def test_stage1_degenerate_loci_stay_finite():
     """Edge cases of the domain: an empty locus, a locus of gaps only, an invariant locus (nothing to estimate: every
     model fits equally, lengths collapse to the lower bound), one informative locus among them, and a 2-taxon tree.
