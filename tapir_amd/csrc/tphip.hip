@@ -61,6 +61,9 @@ int tphip_plan_destroy(tphip_plan* plan) {
     if (plan->d_part) { (void)hipFree(plan->d_part); plan->d_part = nullptr; }
     if (plan->d_col_weight) { (void)hipFree(plan->d_col_weight); plan->d_col_weight = nullptr; }
     if (plan->d_grad_params) { (void)hipFree(plan->d_grad_params); plan->d_grad_params = nullptr; }
+    plan->d_grad2_fops.release(); plan->d_grad2_rops.release();
+    if (plan->d_grad2_ws) { (void)hipFree(plan->d_grad2_ws); plan->d_grad2_ws = nullptr; }
+    if (plan->d_grad2_params) { (void)hipFree(plan->d_grad2_params); plan->d_grad2_params = nullptr; }
     if (plan->d_arena) { (void)hipFree(plan->d_arena); plan->d_arena = nullptr; }
     if (plan->h_arena) { (void)hipHostFree(plan->h_arena); plan->h_arena = nullptr; }
     for (hipEvent_t e : plan->ev) (void)hipEventDestroy(e);
@@ -326,6 +329,28 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
         if (ok) e = p->d_value_tip_node.upload(tip_node);
         p->value_nops = ok ? (int32_t)vops.size() : 0;
         if (ok && e == hipSuccess) e = p->d_value_ops.upload(vops);
+        // the transition-matrix gradient kernel's programs: the same forward stream with a tape slot on every BRANCH, and the
+        // pre-order walk over the internal nodes for the reverse sweep (binary trees only)
+        if (ok && e == hipSuccess) {
+            std::vector<int4> fops(vops);
+            std::vector<int32_t> tape_slot(d->nnodes, -1), tip_pos(d->ntaxa, -1);
+            int32_t nslot = 0, pos = 0;
+            for (int4& o : fops)
+                if ((o.x & OP_CODE_MASK) == OP_BRANCH) { tape_slot[o.y / 128] = nslot; o.z = nslot++; }
+            for (size_t i = 0; i < ops.size(); ++i)
+                if (ops[i].code <= OP_TIP_MUL) tip_pos[ops[i].taxon] = pos++;
+            std::vector<int4> rops;
+            int32_t rdepth = 0;
+            const std::string gerr = build_grad2_program(d->nnodes, d->parent, d->leaf_taxon, tape_slot, tip_pos, &rops, &rdepth);
+            if (gerr.empty() && rdepth <= kGrad2MaxRDepth && !getenv("TPHIP_GRAD_EIGENBASIS")) {
+                e = p->d_grad2_fops.upload(fops);
+                if (e == hipSuccess) e = p->d_grad2_rops.upload(rops);
+                p->grad2_nrops = (int32_t)(rops.size() / 2);
+                p->grad2_ntape = nslot;
+                p->grad2_rdepth = rdepth;
+                p->grad2_ok = e == hipSuccess;
+            }
+        }
     }
     p->nnodes = d->nnodes;
     if (e == hipSuccess) e = p->d_ops.upload(p->prog.ops);
@@ -429,6 +454,19 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
             if (tape_per_block * (size_t)p->num_cus * (size_t)bpc > ((size_t)300 << 20)) bpc = std::min(bpc, 3);
             if (const char* env = getenv("TPHIP_GRAD_BLOCKS_PER_CU")) bpc = std::max(1, atoi(env));
             p->grad_blocks_per_cu = bpc;
+        }
+        // transition-matrix gradient kernel: LDS = tip table + tipY + parked adjoints + per-branch accumulators + state codes
+        if (p->grad2_ok) {
+            p->grad2_lds = ((size_t)p->ntaxa * kValueTipRow + 64 + (size_t)p->grad2_rdepth * 4 * kGrad2Block +
+                            2 * (size_t)kGrad2Waves * p->nnodes) * sizeof(double) + (size_t)p->nwords * kGrad2Block * sizeof(uint32_t);
+            p->grad2_ok = p->value_cols > 0 && p->grad2_lds <= 96 * 1024 &&
+                          (p->grad2_lds <= 64 * 1024 || locus_grad2_kernel_allow_lds(p->prog.stack_depth, 96 * 1024) == hipSuccess);
+            if (p->grad2_ok) {
+                int bpc = 1;
+                if (locus_grad2_kernel_occupancy(p->prog.stack_depth, p->grad2_lds, &bpc) != hipSuccess || bpc < 1) bpc = 1;
+                if (const char* env = getenv("TPHIP_GRAD2_BLOCKS_PER_CU")) bpc = std::max(1, atoi(env));
+                p->grad2_blocks_per_cu = bpc;
+            }
         }
         if (const char* env = getenv("TPHIP_LIK_NSPLIT")) p->lik_nsplit_forced = std::max(1, atoi(env));
         if (const char* fb = getenv("TPHIP_FORCE_BYTE_PATH")) p->force_byte_path = (fb[0] == '1');
@@ -912,6 +950,76 @@ int tphip_locus_gradient_dev(tphip_plan* p, const uint8_t* d_states, int64_t nca
         return fail(TPHIP_ERR_INVALID, "null device pointer");
     if (ncand == 0) return TPHIP_OK;
     HIP_TRY(hipSetDevice(p->device));
+    if (p->grad2_ok && d_states == p->lib_states && p->d_value_packed) {
+        // transition-matrix gradient kernel (locus_grad2_kernel.hpp): eigen-systems, matrices and branch tables of a chunk
+        // of candidates, then resident workgroups loop over (candidate, column slice) items, each with its own tape
+        hipStream_t st = (hipStream_t)stream;
+        const int nsplit = lik_nsplit(p, ncand, kGrad2Block);
+        const size_t nn = (size_t)p->nnodes;
+        const size_t per_cand = (36 + nn * (16 + kGrad2EF)) * sizeof(double);
+        int64_t chunk = std::max<int64_t>(1, (int64_t)(((size_t)4 << 30) / per_cand));
+        chunk = std::min<int64_t>(chunk, ncand);
+        const size_t need_ws = (size_t)chunk * per_cand;
+        if (need_ws > p->grad2_ws_bytes) {
+            if (p->d_grad2_ws) { HIP_TRY(hipFree(p->d_grad2_ws)); p->d_grad2_ws = nullptr; p->grad2_ws_bytes = 0; }
+            HIP_TRY(hipMalloc((void**)&p->d_grad2_ws, need_ws));
+            p->grad2_ws_bytes = need_ws;
+        }
+        double* d_eig = p->d_grad2_ws;
+        double* d_pmat = d_eig + (size_t)chunk * 36;
+        double* d_ef = d_pmat + (size_t)chunk * nn * 16;
+        const size_t items_all = (size_t)ncand * nsplit;
+        if (nsplit > 1) {
+            int rc = grow_part(p, items_all * (8 + (d_dlogt ? nn : 0) + (d_d2logt ? nn : 0)) * sizeof(double));
+            if (rc) return rc;
+        }
+        const int64_t grid_max = (int64_t)p->num_cus * p->grad2_blocks_per_cu;
+        const size_t need_tape = (size_t)std::min<int64_t>((int64_t)std::min<int64_t>(chunk, ncand) * nsplit, grid_max) *
+                                 (size_t)std::max(1, p->grad2_ntape) * 4 * kGrad2Block * sizeof(double);
+        if (need_tape > p->tape_bytes) {
+            if (p->d_tape) { HIP_TRY(hipFree(p->d_tape)); p->d_tape = nullptr; p->tape_bytes = 0; }
+            HIP_TRY(hipMalloc((void**)&p->d_tape, need_tape));
+            p->tape_bytes = need_tape;
+        }
+        if (!p->d_grad2_params) HIP_TRY(hipMalloc((void**)&p->d_grad2_params, sizeof(Grad2Params) * 64));
+        double* o_lnl = nsplit > 1 ? p->d_part : d_lnl;
+        double* o_sum = nsplit > 1 ? p->d_part + items_all : d_sum_dlogt;
+        double* o_dex = nsplit > 1 ? p->d_part + 2 * items_all : d_dexch;
+        double* o_dlt = d_dlogt ? (nsplit > 1 ? p->d_part + 8 * items_all : d_dlogt) : nullptr;
+        double* o_d2 = d_d2logt ? (nsplit > 1 ? p->d_part + (8 + (d_dlogt ? nn : 0)) * items_all : d_d2logt) : nullptr;
+        int slot = 0;
+        for (int64_t done = 0; done < ncand; done += chunk, ++slot) {
+            const int64_t n = std::min<int64_t>(ncand - done, chunk);
+            HIP_TRY(launch_lik_eigen_kernel(st, p->d_models.p, d_cand_locus + done, d_cand_exch + done * 6, n, d_eig));
+            HIP_TRY(launch_lik_pmat_kernel(st, d_eig, d_blen_vecs, d_cand_vec + done, d_cand_scale + done, d_cand_pidx + done,
+                                           d_cand_pfac + done, n, p->nnodes, d_pmat));
+            HIP_TRY(launch_grad2_ef_kernel(st, d_eig, d_blen_vecs, d_cand_vec + done, d_cand_scale + done, d_cand_pidx + done,
+                                           d_cand_pfac + done, n, p->nnodes, d_ef));
+            Grad2Params G2;
+            G2.packed = p->d_value_packed; G2.ncols_total = p->ncols; G2.locus_offsets = p->d_offsets.p; G2.col_weight = p->d_col_weight;
+            G2.models = p->d_models.p; G2.fops = p->d_grad2_fops.p; G2.rops = p->d_grad2_rops.p; G2.nrops = p->grad2_nrops;
+            G2.ntaxa = p->ntaxa; G2.nnodes = p->nnodes; G2.nwords = p->nwords; G2.ntape = p->grad2_ntape; G2.rdepth = p->grad2_rdepth;
+            G2.tip_node = p->d_value_tip_node.p; G2.cand_locus = d_cand_locus + done; G2.eig = d_eig; G2.pmat = d_pmat; G2.ef = d_ef;
+            G2.ncand = n; G2.nsplit = nsplit; G2.tape = p->d_tape;
+            const size_t o = (size_t)done * nsplit;
+            G2.out_lnl = o_lnl + o; G2.out_sum_dlogt = o_sum + o; G2.out_dexch = o_dex + o * 6;
+            G2.out_dlogt = o_dlt ? o_dlt + o * nn : nullptr; G2.out_d2logt = o_d2 ? o_d2 + o * nn : nullptr;
+            if (slot >= 64) { HIP_TRY(hipStreamSynchronize(st)); slot = 0; }   // the parameter blocks in flight are a ring of 64
+            Grad2Params* d_par = (Grad2Params*)p->d_grad2_params + slot;
+            HIP_TRY(hipMemcpyAsync(d_par, &G2, sizeof(Grad2Params), hipMemcpyHostToDevice, st));
+            const int64_t grid = std::min<int64_t>(n * nsplit, grid_max);
+            HIP_TRY(launch_locus_grad2_kernel(p->prog.stack_depth, dim3((unsigned)grid), p->grad2_lds, st, d_par));
+        }
+        if (nsplit > 1) {
+            (void)launch_split_sum_kernel(st, o_lnl, d_lnl, ncand, nsplit, 1);
+            (void)launch_split_sum_kernel(st, o_sum, d_sum_dlogt, ncand, nsplit, 1);
+            (void)launch_split_sum_kernel(st, o_dex, d_dexch, ncand, nsplit, 6);
+            if (d_dlogt) (void)launch_split_sum_kernel(st, o_dlt, d_dlogt, ncand, nsplit, (int)nn);
+            if (d_d2logt) (void)launch_split_sum_kernel(st, o_d2, d_d2logt, ncand, nsplit, (int)nn);
+            HIP_TRY(hipGetLastError());
+        }
+        return TPHIP_OK;
+    }
     GradParams G;
     LikParams& L = G.L;
     L.states = d_states; L.ncols_total = p->ncols; L.locus_offsets = p->d_offsets.p; L.models = p->d_models.p;

@@ -11,6 +11,7 @@
 #include "gtr_model.hpp"
 #include "locus_lik_params.hpp"
 #include "locus_value_params.hpp"
+#include "locus_grad2_params.hpp"
 #include "site_rate_params.hpp"
 #include "tphip.h"
 #include "tree_program.hpp"
@@ -123,6 +124,14 @@ struct tphip_plan {
     char* h_arena = nullptr;
     size_t arena_bytes = 0;
     void* d_grad_params = nullptr;   // device copy of the gradient kernel's parameter block
+    // transition-matrix gradient kernel (locus_grad2_kernel.hpp): binary trees with the value kernel's packed state codes
+    bool grad2_ok = false;
+    DevBuf<int4> d_grad2_fops, d_grad2_rops;
+    int32_t grad2_nrops = 0, grad2_ntape = 0, grad2_rdepth = 0, grad2_blocks_per_cu = 1;
+    size_t grad2_lds = 0;
+    double* d_grad2_ws = nullptr;    // per-candidate transition matrices + branch tables of one chunk of candidates
+    size_t grad2_ws_bytes = 0;
+    void* d_grad2_params = nullptr;
     double* d_col_weight = nullptr;  // optional column multiplicities for the locus likelihood / gradient kernels
     double* d_part = nullptr;   // per-slice partial sums of the locus likelihood / gradient kernels, grown on demand
     size_t part_bytes = 0;
