@@ -21,7 +21,8 @@
 //               and tip children contribute at once with y = U^-1 (state vector) from a 16-entry LDS table.  An internal
 //               child's adjoint is carried in registers to the next record; when both are internal the second is parked in
 //               LDS.  No division anywhere.
-//   per-branch sums over the lanes: wave reduction by shuffles, one lane adds to the wave's row of LDS accumulators.
+//   per-branch sums over the lanes: row sums by data-parallel primitives (no LDS round trip), then the four row leaders of a
+//   wave add to the wave's row of LDS accumulators.
 //
 // Binary trees only (every internal node has two children) and the packed state codes of the value kernel; anything else
 // runs locus_grad_kernel.  Bound: FP64 VALU, ~150 instructions per internal branch and ~75 per tip branch per column
@@ -69,13 +70,27 @@ __global__ __launch_bounds__(128) void grad2_ef_kernel(const double* eig, const 
     out[11] = 0.0;
 }
 
-__device__ inline void g2_wave_sum2(double& a, double& b) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+typedef double __attribute__((address_space(1)))* g2_gptr;             // global address space: plain global_load / global_store, not flat
+typedef const uint32_t __attribute__((address_space(1)))* g2_gcu32;
+
+// v of lane i += v of lane i - n within its row of 16 lanes (zero beyond the row's start): data-parallel primitives on the two
+// halves of the double, no LDS round trip
+template <int CTRL>
+__device__ inline double g2_dpp_add(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+// row sums of two values: afterwards lanes 15, 31, 47, 63 hold the sums of their 16 lanes
+__device__ inline void g2_row_sum2(double& a, double& b) {
+    a = g2_dpp_add<0x111>(a); b = g2_dpp_add<0x111>(b);   // row_shr:1
+    a = g2_dpp_add<0x112>(a); b = g2_dpp_add<0x112>(b);   // row_shr:2
+    a = g2_dpp_add<0x114>(a); b = g2_dpp_add<0x114>(b);   // row_shr:4
+    a = g2_dpp_add<0x118>(a); b = g2_dpp_add<0x118>(b);   // row_shr:8
 }
 
 template <int D>
-__global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2Params* __restrict__ Gp) {
+__global__ __launch_bounds__(kGrad2Block, 3) void locus_grad2_kernel(const Grad2Params* __restrict__ Gp) {
     const Grad2Params& G = *Gp;
     extern __shared__ double lds[];
     const int nn = G.nnodes;
@@ -88,7 +103,8 @@ __global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2
     __shared__ double eig[36];
     __shared__ double red[kGrad2Waves * 12];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double* tape = G.tape + (size_t)blockIdx.x * (size_t)(G.ntape > 0 ? G.ntape : 1) * 4 * kGrad2Block + tid;
+    const g2_gptr tape = (g2_gptr)(uintptr_t)G.tape + (size_t)blockIdx.x * (size_t)(G.ntape > 0 ? G.ntape : 1) * 4 * kGrad2Block + tid;
+    const g2_gcu32 packed = (g2_gcu32)(uintptr_t)G.packed;
     double* gw = gacc + (size_t)wave * nn;
     double* hw = hacc + (size_t)wave * nn;
     const int64_t nitems = G.ncand * G.nsplit;
@@ -162,8 +178,8 @@ __global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2
             const double p0 = lam[0] * d0, p1 = lam[1] * d1, p2 = lam[2] * d2, p3 = lam[3] * d3;
             double c = (p0 + p1) + (p2 + p3);                                                      // w L'/L of this column
             double h = fma(lam[3], p3, fma(lam[2], p2, fma(lam[1], p1, lam[0] * p0))) - c * c * inv_w;   // w (L''/L - (L'/L)^2)
-            g2_wave_sum2(c, h);
-            if (lane == 0) { gw[node] += c; hw[node] += h; }
+            g2_row_sum2(c, h);
+            if ((lane & 15) == 15) { atomicAdd(gw + node, c); atomicAdd(hw + node, h); }   // four lanes per wave, LDS
         };
 
         for (int64_t base = lo; base < hi; base += kGrad2Block) {
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2
             const bool active = colx < hi;
             const int64_t col = active ? colx : lo;
 #pragma unroll 4
-            for (int w = 0; w < G.nwords; ++w) msk[(size_t)w * kGrad2Block + tid] = G.packed[(size_t)w * G.ncols_total + col];
+            for (int w = 0; w < G.nwords; ++w) msk[(size_t)w * kGrad2Block + tid] = packed[(size_t)w * G.ncols_total + col];
             // ---------------- forward (locus_value_kernel's sweep, one column per thread) ----------------
             double acc[4] = {1.0, 1.0, 1.0, 1.0};
             double stk[D][4];
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         n[i] = fma(Pb[12 + i], acc[3], fma(Pb[8 + i], acc[2], fma(Pb[4 + i], acc[1], Pb[i] * acc[0])));
-                    double* slot = tape + (size_t)op.z * 4 * kGrad2Block;   // the branch's message: what the reverse sweep reads
+                    const g2_gptr slot = tape + (size_t)op.z * 4 * kGrad2Block;   // the branch's message: what the reverse sweep reads
 #pragma unroll
                     for (int i = 0; i < 4; ++i) slot[i * kGrad2Block] = n[i];
                     if (pop) {
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2
                     cdA = (msk[(size_t)(b4.x & 0xffff) * kGrad2Block + tid] >> (b4.x >> 16)) & 15u;
                     tip_msg(a4.z, cdA, mA);
                 } else {
-                    const double* slot = tape + (size_t)a4.z * 4 * kGrad2Block;
+                    const g2_gptr slot = tape + (size_t)a4.z * 4 * kGrad2Block;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mA[i] = slot[i * kGrad2Block];
                 }
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2
                     cdB = (msk[(size_t)(b4.y & 0xffff) * kGrad2Block + tid] >> (b4.y >> 16)) & 15u;
                     tip_msg(a4.w, cdB, mB);
                 } else {
-                    const double* slot = tape + (size_t)a4.w * 4 * kGrad2Block;
+                    const g2_gptr slot = tape + (size_t)a4.w * 4 * kGrad2Block;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mB[i] = slot[i * kGrad2Block];
                 }
@@ -355,13 +371,17 @@ __global__ __launch_bounds__(kGrad2Block, 2) void locus_grad2_kernel(const Grad2
                     double x[4];
                     mulUt(uA, x);
                     const unsigned mk = (unsigned)((kValueMaskOfCode >> (4 * cdA)) & 15ull);
-                    contribute(b4.z & 0xffff, x, tipY + mk * 4, nullptr);
+                    const double2 y01 = *(const double2*)(tipY + mk * 4), y23 = *(const double2*)(tipY + mk * 4 + 2);
+                    const double y[4] = {y01.x, y01.y, y23.x, y23.y};
+                    contribute(b4.z & 0xffff, x, y, nullptr);
                 }
                 if (flags & G2_B_TIP) {
                     double x[4];
                     mulUt(uB, x);
                     const unsigned mk = (unsigned)((kValueMaskOfCode >> (4 * cdB)) & 15ull);
-                    contribute((b4.z >> 16) & 0xffff, x, tipY + mk * 4, nullptr);
+                    const double2 y01 = *(const double2*)(tipY + mk * 4), y23 = *(const double2*)(tipY + mk * 4 + 2);
+                    const double y[4] = {y01.x, y01.y, y23.x, y23.y};
+                    contribute((b4.z >> 16) & 0xffff, x, y, nullptr);
                 }
                 if (flags & G2_PUSH_B) {
                     double* as_ = astack + ((size_t)rsp * 4) * kGrad2Block + tid;
