@@ -1102,6 +1102,59 @@ def test_compress_columns_exact_and_weighted_likelihood(oracle):
     assert same[0].shape == (3, 2) and list(same[2]) == [400, 600] and list(same[1]) == [0, 1, 2]
 
 
+def test_locus_gradient_kernels_agree(oracle):
+    """The two gradient kernels: the transition-matrix one (locus_grad2_kernel: taken when the alignment is the library's
+    cached copy, whose packed state codes it reads, and the tree is binary) and the eigenbasis one (locus_grad_kernel: any
+    caller-owned array, any tree) compute the same numbers by different routes -- value, six rate derivatives, every branch
+    derivative and curvature within 1e-10 of the largest entry -- on 5 ... 300 taxa (rescaled partials at 300), with column
+    weights, gaps and ambiguity codes, zero-length and long branches, equal eigenvalues, and a column count that leaves
+    padding lanes.  Finite differences of the oracle pin one of them (test above); a polytomy takes the eigenbasis kernel
+    with or without the cache."""
+    engine = _engine()
+    from tapir_amd import newick, synth
+    rng = np.random.default_rng(23)
+    for ntaxa, nloci, ncols in ((5, 3, 77), (16, 4, 333), (64, 2, 1000), (300, 1, 140)):
+        d = synth.simulate(nloci, ncols, ntaxa, 200 + ntaxa, rate_mean=0.01)
+        pin = synth.plan_inputs(d["root"], d["names"])
+        st = d["states"].numpy().copy()
+        st[rng.random(st.shape) < 0.02] = rng.choice(np.array([3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15], np.uint8))
+        plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], d["pi"], d["exch"], 3, [1], [[0, 1]])
+        nn = len(pin["parent"])
+        ncand = 7
+        cl = rng.integers(0, nloci, ncand)
+        ce = np.exp(rng.normal(0, 0.5, (ncand, 6)))
+        ce[0] = 1.0
+        cb = np.asarray(pin["blen"])[None, :] * np.exp(rng.normal(-3.5, 1.0, (ncand, nn)))
+        cb[1, rng.integers(0, nn - 1, 3)] = 0.0
+        cb[2, rng.integers(0, nn - 1, 2)] = 4.0
+        w = rng.integers(1, 5, st.shape[1]).astype(float)
+        for weights in (None, w):
+            plan.set_column_weights(weights)
+            old = plan.locus_gradient(st, cb, cl, ce, curvature=True)
+            cache = plan.device_cache()
+            new = plan.locus_gradient(st, cb, cl, ce, curvature=True, cache=cache)
+            val = plan.locus_loglik(st, cb, cl, ce, cache=cache)
+            cache.release()
+            assert np.max(np.abs(new[0] - val) / np.abs(val)) < 1e-13
+            for name, a, b in zip(("lnl", "dexch", "dlogt", "sum_dlogt", "d2logt"), old, new):
+                assert np.all(np.isfinite(b)), name
+                assert np.max(np.abs(a - b)) <= 1e-10 * max(np.abs(a).max(), 1e-12), (ntaxa, name, np.max(np.abs(a - b)), np.abs(a).max())
+        plan.close()
+    root = newick.parse("((a:1,b:2):1,(c:1,d:1.5):2,(e:0.5,f:1):1,g:3);")
+    names = [n.name for n in newick.leaves(root)]
+    parent, blen, leaf = newick.to_arrays(root, names)
+    st = rng.choice(np.array([1, 2, 4, 8, 15, 5], dtype=np.uint8), size=(len(names), 97))
+    plan = engine.Plan(len(names), parent, blen, leaf, [0, 97], [[0.1, 0.2, 0.3, 0.4]], [np.ones(6)], 3, [1], [[0, 1]])
+    b = np.asarray(blen)[None, :] * 0.1
+    old = plan.locus_gradient(st, b, [0], [np.ones(6)], curvature=True)
+    cache = plan.device_cache()
+    new = plan.locus_gradient(st, b, [0], [np.ones(6)], curvature=True, cache=cache)
+    cache.release()
+    plan.close()
+    for a, c in zip(old, new):
+        assert np.array_equal(a, c)
+
+
 def test_locus_gradient_hessian_diagonal(oracle):
     """d2 lnL / d (log t_b)^2 from the gradient kernel against second central differences of the oracle likelihood."""
     engine = _engine()
