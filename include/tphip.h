@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TPHIP_VERSION 100 /* 0.1.0 */
+#define TPHIP_VERSION 110 /* 0.1.1: tphip_plan_desc.struct_size, TPHIP_START_AUTO, tphip_stage1_fit, tphip_plan_set_models */
 
 enum {
     TPHIP_OK = 0,
@@ -63,10 +63,11 @@ enum {
     TPHIP_INTEG_CLOSED = 1    /* analytic antiderivative -(4rt+1)exp(-4rt); error column = 0            */
 };
 
-/* tphip_plan_desc.start_rule */
+/* tphip_plan_desc.start_rule: where the per-site optimiser starts (HyPhy: siteRate = 1 before every Optimize, bf:1050) */
 enum {
-    TPHIP_START_PARSIMONY = 0, /* the column's parsimony rate (default)                                */
-    TPHIP_START_REFERENCE = 1  /* siteRate = 1, HyPhy's start value (bf:1050)                          */
+    TPHIP_START_AUTO = 0,      /* default: HyPhy's start on trees of fewer than 32 taxa, the parsimony start from 32 on    */
+    TPHIP_START_REFERENCE = 1, /* siteRate = 1 on every tree                                                            */
+    TPHIP_START_PARSIMONY = 2  /* the column's parsimony rate on every tree (one evaluation fewer per column)           */
 };
 
 /* tphip_plan_desc.pattern_dedup */
@@ -86,6 +87,9 @@ int tphip_device_count(void);
 typedef struct tphip_plan tphip_plan;
 
 typedef struct tphip_plan_desc {
+    uint32_t struct_size;      /* sizeof(tphip_plan_desc) as the caller compiled it.  Zero-initialise the struct, then set
+                                  this: fields the caller's header did not have yet take their zero defaults instead of being
+                                  read from beyond the caller's struct                                   */
     int32_t device;            /* HIP device ordinal (>= 0)                                            */
     /* tree (host pointers) */
     int32_t ntaxa;             /* rows of the alignment                                                */
@@ -117,10 +121,11 @@ typedef struct tphip_plan_desc {
     const double *cat_rate;    /* [ncat] rate multipliers > 0 (mean 1 keeps `rate` = kappa * s interpretable) */
     const double *cat_weight;  /* [ncat] weights > 0 (normalised by the library)                       */
     /* Where the per-site optimiser starts.  HyPhy starts every column at siteRate = 1 (bf:1050) and returns the local
-     * optimum uphill of that point.  TPHIP_START_PARSIMONY starts at the column's parsimony rate instead:
-     * one evaluation fewer per column and the same maximum on every unimodal column; on the rare multimodal ones
-     * (measured: 0 of 4e5 columns at 64 taxa, 6e-5 at 16 taxa, 1e-3 of noisy 5-taxon columns: DESIGN.md section 5)
-     * it may end on another local optimum than a search from 1 would.  TPHIP_START_REFERENCE starts at siteRate = 1. */
+     * optimum uphill of that point.  The parsimony start (the column's parsimony rate) saves one evaluation
+     * per column and reaches the same maximum on every unimodal column; on the rare multimodal ones it may end on another
+     * local optimum than a search from 1 would -- measured: 0 of 4e5 columns at 64 taxa, 6e-5 at 16 taxa, 1e-3 of noisy
+     * 5-taxon columns.  TPHIP_START_AUTO therefore uses it only on trees of 32 taxa or more, where no
+     * deviation was ever seen, and HyPhy's own start below; the other two values force one rule on every tree. */
     int32_t start_rule;        /* TPHIP_START_*                                                        */
     /* HyPhy fits one rate per UNIQUE column pattern of a locus and reports it for every column that carries it
      * (bf:1033-1044: GetDataInfo(dupInfo...), alreadyDone[siteMap]).  TPHIP_DEDUP_AUTO does the same wherever a cheap

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -156,9 +157,17 @@ static int make_parts(tphip_plan* p) {
     return TPHIP_OK;
 }
 
-int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
-    if (!d || !out) return fail(TPHIP_ERR_INVALID, "null plan descriptor");
+int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
+    if (!d_in || !out) return fail(TPHIP_ERR_INVALID, "null plan descriptor");
     *out = nullptr;
+    // the caller's struct may be shorter (built against an older header): its missing trailing fields are zero
+    if (d_in->struct_size < offsetof(tphip_plan_desc, round_decimals) + sizeof(int32_t) || d_in->struct_size > 4096)
+        return fail(TPHIP_ERR_INVALID, "tphip_plan_desc.struct_size not set (zero-initialise the struct, then set it to sizeof)");
+    tphip_plan_desc d_copy;
+    memset(&d_copy, 0, sizeof(d_copy));
+    memcpy(&d_copy, d_in, std::min<size_t>(d_in->struct_size, sizeof(d_copy)));
+    d_copy.struct_size = (uint32_t)sizeof(d_copy);
+    const tphip_plan_desc* d = &d_copy;
     int ndev = tphip_device_count();
     if (ndev <= 0) return fail(TPHIP_ERR_NO_DEVICE, "no HIP device visible: libtphip has no CPU path");
     if (d->device < 0 || d->device >= ndev) return fail(TPHIP_ERR_INVALID, "device ordinal out of range");
@@ -170,7 +179,7 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     if (!(d->correction > 0.0)) return fail(TPHIP_ERR_INVALID, "correction must be > 0");
     if (d->integ_mode != TPHIP_INTEG_QUADPACK && d->integ_mode != TPHIP_INTEG_CLOSED)
         return fail(TPHIP_ERR_INVALID, "unknown integ_mode");
-    if (d->start_rule != TPHIP_START_PARSIMONY && d->start_rule != TPHIP_START_REFERENCE)
+    if (d->start_rule != TPHIP_START_AUTO && d->start_rule != TPHIP_START_PARSIMONY && d->start_rule != TPHIP_START_REFERENCE)
         return fail(TPHIP_ERR_INVALID, "unknown start_rule");
     if (d->pattern_dedup != TPHIP_DEDUP_AUTO && d->pattern_dedup != TPHIP_DEDUP_OFF && d->pattern_dedup != TPHIP_DEDUP_ON)
         return fail(TPHIP_ERR_INVALID, "unknown pattern_dedup");
@@ -213,7 +222,9 @@ int tphip_plan_create(const tphip_plan_desc* d, tphip_plan** out) {
     p->device = d->device; p->ntaxa = d->ntaxa; p->nloci = d->nloci; p->ncols = ncols;
     p->T = d->T; p->n_t = d->n_t; p->n_i = d->n_i; p->integ_mode = d->integ_mode;
     p->threshold = d->threshold; p->round_decimals = d->round_decimals; p->correction = d->correction;
-    p->start_rule = d->start_rule;
+    // TPHIP_START_AUTO: HyPhy's own start where the parsimony start was ever seen to end on another local optimum (small trees)
+    p->start_rule = d->start_rule == TPHIP_START_AUTO ? (d->ntaxa >= kFirstStepMinTaxa ? TPHIP_START_PARSIMONY : TPHIP_START_REFERENCE)
+                                                      : d->start_rule;
     p->dedup_mode = d->pattern_dedup;
     p->ncat = cat.empty() ? 0 : d->ncat;
     std::string terr = build_tree_program(d->ntaxa, d->nnodes, d->parent, d->branch_len, d->leaf_taxon, &p->prog);
@@ -1228,16 +1239,18 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
                        is_pinned(states) && is_pinned(rate) && is_pinned(subst) && is_pinned(lnl) && is_pinned(flag) &&
                        is_pinned(nres) && (!do_pi || (tables && is_pinned(tables)));
     if (!split) {
-        int rc = host_enqueue(p, states, (size_t)p->ncols, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables,
-                              do_site, do_pi);
-        if (rc) return rc;
-        return host_wait(p);
+        // always drain: a failed enqueue may already have copies in flight that touch the caller's buffers
+        const int rc = host_enqueue(p, states, (size_t)p->ncols, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables,
+                                    do_site, do_pi);
+        const int rw = host_wait(p);
+        return rc ? rc : rw;
     }
     int rc = make_parts(p);
     if (rc) return rc;
     if (p->parts.empty()) {   // the batch does not cut into groups with columns
         rc = host_enqueue(p, states, (size_t)p->ncols, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables, do_site, do_pi);
-        return rc ? rc : host_wait(p);
+        const int rw = host_wait(p);
+        return rc ? rc : rw;
     }
     const size_t W = (size_t)tphip_plan_table_width(p);
     p->last_run_in_parts = true;

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TPHIP_LIB") or os.path.join(_HERE, "libtphip.so")
 
 FLAG_OK, FLAG_FLAT, FLAG_SATURATED, FLAG_ZERO, FLAG_MAXIT = 0, 1, 2, 3, 4
-START_PARSIMONY, START_REFERENCE = 0, 1
+START_AUTO, START_REFERENCE, START_PARSIMONY = 0, 1, 2
 DEDUP_AUTO, DEDUP_OFF, DEDUP_ON = 0, 1, 2
 INTEG_QUADPACK, INTEG_CLOSED = 0, 1
 
@@ -28,7 +28,7 @@ class TphipError(Exception):
 
 
 class PlanDesc(ctypes.Structure):
-    _fields_ = [("device", _i32), ("ntaxa", _i32), ("nnodes", _i32), ("parent", _vp), ("branch_len", _vp),
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", _i32), ("ntaxa", _i32), ("nnodes", _i32), ("parent", _vp), ("branch_len", _vp),
                 ("leaf_taxon", _vp), ("nloci", _i64), ("locus_offsets", _vp), ("pi", _vp), ("exch", _vp),
                 ("T", _i32), ("times", _vp), ("n_t", _i32), ("intervals", _vp), ("n_i", _i32),
                 ("integ_mode", _i32), ("correction", _f64), ("threshold", _i32), ("round_decimals", _i32),
@@ -203,7 +203,7 @@ class Plan:
 
     def __init__(self, ntaxa, parent, branch_len, leaf_taxon, locus_offsets, pi, exch, T, times, intervals,
                  correction=1.0, threshold=3, round_decimals=4, integ_mode=INTEG_QUADPACK, device=0, cat_rates=None,
-                 cat_weights=None, start_rule=START_PARSIMONY, pattern_dedup=DEDUP_AUTO):
+                 cat_weights=None, start_rule=START_AUTO, pattern_dedup=DEDUP_AUTO):
         lib = load()
         self._lib = lib
         self._h = _vp()
@@ -223,7 +223,7 @@ class Plan:
             raise TphipError("pi must be [L,4] and exch [L,6] for L = len(locus_offsets) - 1")
         if k["iv"].size % 2:
             raise TphipError("intervals must be (start, stop) pairs")
-        d = PlanDesc(device=device, ntaxa=ntaxa, nnodes=len(k["parent"]), parent=k["parent"].ctypes.data,
+        d = PlanDesc(struct_size=ctypes.sizeof(PlanDesc), device=device, ntaxa=ntaxa, nnodes=len(k["parent"]), parent=k["parent"].ctypes.data,
                      branch_len=k["blen"].ctypes.data, leaf_taxon=k["leaf"].ctypes.data, nloci=self.nloci,
                      locus_offsets=k["off"].ctypes.data, pi=k["pi"].ctypes.data, exch=k["exch"].ctypes.data, T=int(T),
                      times=k["times"].ctypes.data, n_t=k["times"].size, intervals=k["iv"].ctypes.data,

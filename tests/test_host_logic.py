@@ -314,7 +314,29 @@ def test_cabi_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", engine.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (tphip_[a-z_0-9]+)$", nm, flags=re.M))
     assert exported == declared, (exported ^ declared)
-    assert lib.tphip_version() == 100
+    assert lib.tphip_version() == 110
+
+
+def test_structurizer_switch_touches_only_the_kernels_it_is_meant_for():
+    """`-mllvm -structurizecfg-skip-uniform-regions=true` (a default-off LLVM switch that once mis-merged two stores in a
+    helper kernel) is confined to translation units of their own.  Every flagged unit is compiled to
+    gfx950 assembly with and without it: the functions whose code changes must be the interpreter-style kernels the switch is
+    there for, and every other function of those units must come out byte-identical -- so a helper kernel that moves into
+    such a unit cannot be affected silently (tools/flag_containment.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import flag_containment as fc
+    units = fc.flagged_units()
+    assert sorted(units) == ["locus_grad2_launch.hip", "locus_value_launch.hip", "site_rate_launch.hip"]
+    meant = {"site_rate_launch.hip": ("tphip::site_rate_kernel<", "tphip::eval_columns_kernel("),   # (the diagnostic twin of the
+             "locus_value_launch.hip": ("tphip::locus_value_kernel<",),                                #  site-rate evaluation)
+             "locus_grad2_launch.hip": ("tphip::locus_grad2_kernel<",)}
+    for u in units:
+        changed, every = fc.changed_kernels(u)
+        assert changed, u                                  # the switch does something for the unit, or it should go
+        for k in changed:
+            assert any(m in k for m in meant[u]), (u, k)
+        helpers = [k for k in every if not any(m in k for m in meant[u])]
+        assert helpers and all(k not in changed for k in helpers), (u, helpers)
 
 
 def test_one_hip_runtime_whatever_the_import_order():
