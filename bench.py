@@ -31,6 +31,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# This pool's host driver supports dmabuf IPC only: without the variable RCCL's handle exchange between the ranks of one
+# node fails with `hipIpcGetMemHandle: invalid argument`.  It is exported on the boxes already; set here (before torch
+# loads the runtime) so that a launch from a bare environment behaves like every rehearsal did.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak
@@ -83,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5"],
+    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5", "R1"],
                     help="default: C3 on one GPU (the headline), C4 dealt over the ranks when --gpus > 1")
     ap.add_argument("--loci", type=int, default=None, help="override the number of loci of the config (experiments)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration per leg (0 = skip)")
@@ -99,6 +103,8 @@ def main():
                     help="N > 1: skip rank 0's run of the whole config (the bit-identity check of the gathered table)")
     args = ap.parse_args()
 
+    if args.workload == "R1":
+        return real_data_workload(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
@@ -276,7 +282,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "strong" if world > 1 else "none",   # N = 1 is neither weak nor strong scaling
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic (seeded Yule tree, GTR-simulated columns, Gamma(0.5) site rates, 5% gaps; SURVEY.md 8d)",
@@ -334,6 +340,80 @@ def main():
         dist.destroy_process_group()
     if parity_failure:
         raise SystemExit("PARITY FAILURE (GPU vs CPU oracle on the bench's own columns): " + parity_failure)
+
+
+def real_data_workload(args):
+    """--workload R1: a real-data-shaped batch.  The synthetic configs repeat almost no column (5 % random gaps), so the
+    one-fit-per-unique-pattern machinery (HyPhy: GetDataInfo(dupInfo...), alreadyDone[siteMap], models_and_rates.bf:1033-1044;
+    here csrc/pattern_kernels.hpp) is idle in them.  R1 = bootstrap resamples of the reference's bundled locus
+    (tests/golden/chr1_918.nex, 5 taxa x 226 columns, 57 patterns) on its tree, 512 loci x 2048 columns = 2^20 columns, with
+    the PhyDesign parameters of the known-answer file; the line carries `dedup` = the same pass with de-duplication off and
+    automatic (bit-identical outputs are required)."""
+    import torch
+    from tapir_amd import compute, engine, newick, nexus
+    g = os.path.join(ROOT, "tests", "golden")
+    names, states = nexus.read_states(os.path.join(g, "chr1_918.nex"))
+    root = newick.read_tree(os.path.join(g, "Euteleost.tree"))
+    depth, factor = compute.correct_tree(root)
+    parent, blen, leaf = newick.to_arrays(root, names)
+    kat = json.load(open(os.path.join(g, "chr1_918_phydesign_rates.json")))
+    pi = np.array(kat["freqs_ACGT"])
+    exch = np.array([kat[k] for k in ("AC", "AG", "AT", "CG", "CT", "GT")])
+    L, S = args.loci or 512, 2048
+    rng = np.random.default_rng(20261004)
+    st = np.ascontiguousarray(np.concatenate([states[:, rng.integers(0, states.shape[1], S)] for _ in range(L)], axis=1))
+    uniq = np.mean([len({st[:, l * S + c].tobytes() for c in range(S)}) for l in range(min(L, 32))]) / S
+    off = np.arange(L + 1, dtype=np.int64) * S
+    dev = torch.device("cuda", 0)
+    d_states = torch.from_numpy(st).to(dev)
+    times, intervals = [10, 20, 50], [[0, 10], [20, 100]]
+    res = {}
+    for name, mode in (("off", engine.DEDUP_OFF), ("auto", engine.DEDUP_AUTO)):
+        plan = engine.Plan(len(names), parent, blen, leaf, off, np.tile(pi, (L, 1)), np.tile(exch, (L, 1)), int(depth), times, intervals,
+                           correction=factor, pattern_dedup=mode)
+        n = plan.ncols
+        B = dict(rate=torch.empty(n, dtype=torch.float64, device=dev), subst=torch.empty(n, dtype=torch.float64, device=dev),
+                 lnl=torch.empty(n, dtype=torch.float64, device=dev), flag=torch.empty(n, dtype=torch.uint8, device=dev),
+                 nres=torch.empty(n, dtype=torch.int32, device=dev), tables=torch.empty((L, plan.width), dtype=torch.float64, device=dev),
+                 ws=torch.empty(plan.workspace_bytes, dtype=torch.uint8, device=dev))
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(args.warmup):
+            plan.run_dev(d_states, B["rate"], B["subst"], B["lnl"], B["flag"], B["nres"], B["tables"], B["ws"], stream)
+        torch.cuda.synchronize()
+        plan.profile_enable(True)
+        plan.profile_read(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            plan.run_dev(d_states, B["rate"], B["subst"], B["lnl"], B["flag"], B["nres"], B["tables"], B["ws"], stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        site_ms, pi_ms, launches = plan.profile_read(reset=True)
+        res[name] = dict(ms=1e3 * dt / args.steps, site_ms=site_ms / max(1, launches), evals=plan.last_eval_count(),
+                         out={k: B[k].cpu().numpy() for k in ("rate", "subst", "lnl", "flag", "nres", "tables")})
+        plan.close()
+    for k in res["off"]["out"]:
+        if not np.array_equal(res["off"]["out"][k], res["auto"]["out"][k], equal_nan=True):
+            raise SystemExit("PARITY FAILURE: de-duplication changed `%s`" % k)
+    n = L * S
+    a = res["auto"]
+    alg = n * (len(names) + 24)
+    print(json.dumps({
+        "metric": "alignment columns/sec (site-rate+PI)", "value": n / (a["ms"] * 1e-3), "unit": "columns/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": a["ms"], "higher_is_better": True, "scaling": "none",
+        "vs_baseline": None, "dtype": "f64",
+        "data": "bootstrap resamples of tapir/tests/test-data/chr1_918.nex (committed fixture) on Euteleost.tree, PhyDesign parameters",
+        "config": {"workload": "R1: %d loci x %d resampled columns x %d taxa (real-data-shaped: %.1f %% of a locus' columns are "
+                               "distinct patterns), T=%d, %d --times, %d --intervals" % (L, S, len(names), 100 * uniq, int(depth),
+                                                                                        len(times), len(intervals)),
+                   "total_columns": n},
+        "roofline": {"bound": "hbm", "kernel": "site_rate_kernel", "achieved": alg / (a["site_ms"] * 1e-3) / 1e9 if a["site_ms"] else 0.0,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (alg / (a["site_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if a["site_ms"] else 0.0,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_avg_ms": a["site_ms"]},
+        "cpu_baseline": None,
+        "dedup": {"unique_fraction": uniq, "evals_off": res["off"]["evals"], "evals_auto": a["evals"],
+                  "site_ms_off": res["off"]["site_ms"], "site_ms_auto": a["site_ms"], "step_ms_off": res["off"]["ms"],
+                  "step_ms_auto": a["ms"], "outputs_bit_identical": True},
+    }))
 
 
 def stage1_sample(data, pin, nl, ncols, ntaxa, times, intervals):
@@ -430,6 +510,55 @@ def cpu_baseline(pool, workers, data, pin, nloci, ncols, ntaxa, times, intervals
         out["all_cores"] = {"value": len(jobs) * per_task / wall, "unit": "columns/s", "cores": workers,
                             "sample": "%d tasks of %d columns (one locus each) over %d forked oracle workers, %.1f s wall, "
                                       "%.1f s of CPU work" % (len(jobs), per_task, workers, wall, sum(r[0] for r in results))}
+    # ---- leg 3: the cost structure of the reference's own PI stage -- a dense (T, S) matrix,
+    # nansum, and one scipy.integrate.quad per (site, interval) summed in Python (tapir/compute.py:46-52, 76-94) -- written
+    # here with numpy / scipy on the rates the GPU just produced for one whole locus (so its row of the GPU's PI table is
+    # comparable); reported per column, an extrapolation from that locus.  Skipped where scipy is not installed.
+    try:
+        from scipy import integrate as _integrate
+    except ImportError:
+        _integrate = None
+    if _integrate is not None and args.gamma_categories <= 1:
+        from tapir_amd import compute
+        l3 = min(nloci - 1, 1)
+        c3 = ncols
+        raw = d_rate[l3 * ncols:l3 * ncols + c3].cpu().numpy()
+        nres = d_nres[l3 * ncols:l3 * ncols + c3].cpu().numpy()
+        rates = compute.round_like_hyphy(raw, 4) / pin["correction"]
+        rates = np.where(nres >= 3, rates, np.nan)
+
+        def townsend(t, r):
+            return 16.0 * r * r * t * np.exp(-4.0 * r * t)
+
+        t0 = time.perf_counter()
+        tv = np.arange(T, dtype=np.float64)[:, None]
+        net = np.nansum(townsend(tv, rates[None, :]), axis=1)
+        fin = rates[np.isfinite(rates)]
+        epochs = []
+        budget = max(2.0, args.cpu_seconds)          # seconds for the quad calls; beyond it the leg extrapolates further
+        used_sites = len(fin)
+        for (a, b) in intervals:
+            vals = []
+            for k, r in enumerate(fin):
+                vals.append(_integrate.quad(townsend, a, b, args=(r,)))
+                if k % 1024 == 1023 and time.perf_counter() - t0 > budget * (len(epochs) + 1) / len(intervals):
+                    used_sites = min(used_sites, k + 1)
+                    break
+            epochs.append((sum(v[0] for v in vals), sum(v[1] for v in vals), len(vals)))
+        dt3 = time.perf_counter() - t0
+        frac = sum(e[2] for e in epochs) / max(1, len(intervals) * len(fin))
+        leg3 = {"value": c3 * frac / dt3, "unit": "columns/s", "cores": 1, "kind": "port",
+                "sample": "locus %d of the same batch (%d columns, %d finite rates), %.0f %% of its (site, interval) quad calls in "
+                          "%.1f s: extrapolated to the whole batch; numpy (T, S) matrix + nansum + scipy.integrate.quad per site "
+                          "and interval (PI stage only, no site-rate ML)" % (l3, c3, len(fin), 100 * frac, dt3)}
+        if frac == 1.0:   # every call made: this is what the reference's PI stage would store for the locus
+            row = d_tables[l3].cpu().numpy()
+            n_t, n_i = len(times), len(intervals)
+            ref = np.concatenate([net, net[np.asarray(times, dtype=np.int64)], [e[0] for e in epochs]])
+            rel = float(np.max(np.abs(row[:T + n_t + n_i] - ref)) / max(1e-300, np.abs(ref).max()))
+            leg3["gpu_table_row_max_rel_diff"] = rel
+            par["scipy_table_max_rel"] = rel
+        out["numpy_scipy_pi"] = leg3
     out["parity_sample"] = par
     failure = None
     if par["flag_mismatches"] or par["nres_mismatches"]:
@@ -438,6 +567,8 @@ def cpu_baseline(pool, workers, data, pin, nloci, ncols, ntaxa, times, intervals
         failure = "site rates differ by %.3g relative (tolerance 1e-6)" % par["max_rel_rate"]
     elif par["tables_max_rel"] > 1e-9:
         failure = "PI table rows differ by %.3g relative (tolerance 1e-9)" % par["tables_max_rel"]
+    elif par.get("scipy_table_max_rel", 0.0) > 1e-9:
+        failure = "PI table row differs from numpy + scipy.integrate.quad by %.3g relative (tolerance 1e-9)" % par["scipy_table_max_rel"]
     return out, failure
 
 

@@ -248,8 +248,10 @@ __global__ __launch_bounds__(256) void dedup_resolve_kernel(DedupParams P) {
     for (int j = 0; j < 4; ++j) {
         const int64_t c = base + j * 256 + threadIdx.x;
         if (c >= hi) continue;
-        // (dup_of is written by plain stores on each path, not through one merged value: the hipcc of ROCm 7.2 lost the
-        //  representative in the phi of `rep = same ? r : -1` after the comparison loop -- IR right, ISA wrong)
+        // (dup_of is written by plain stores on each path, not through one merged value `rep = same ? r : -1` stored after the
+        //  branch.  Round 2 saw wrong representatives with the merged form inside this kernel and took it for a compiler
+        //  fault; a stand-alone twin of both forms, tools/microbench/dedup_phi_repro.hip, gives right answers for BOTH on
+        //  ROCm 7.2, so the claim is unproven -- the two forms are equivalent and this one is kept)
         P.dup_of[c] = -1;
         if (on && P.flag[c] == TPHIP_FLAG_OK) {
             const unsigned long long h = dedup_key(P.hash[c]);

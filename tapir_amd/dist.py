@@ -12,6 +12,9 @@ process per GPU, launched by torch.distributed.run.
 """
 import os
 
+# (multi-process GPU work on this pool needs dmabuf IPC; see bench.py)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 

@@ -159,7 +159,7 @@ _PORT = [29630]
 
 def _bench(argv, nproc=None, timeout=900):
     _PORT[0] += 1   # a fresh rendezvous port per launch
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ)   # (bench.py sets HSA_ENABLE_IPC_MODE_LEGACY=0 itself: dmabuf IPC for RCCL on this pool)
     if nproc is None:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + argv
     else:
