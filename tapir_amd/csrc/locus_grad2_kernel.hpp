@@ -89,8 +89,11 @@ __device__ inline void g2_row_sum2(double& a, double& b) {
     a = g2_dpp_add<0x118>(a); b = g2_dpp_add<0x118>(b);   // row_shr:8
 }
 
+#ifndef TPHIP_GRAD2_MIN_WAVES
+#define TPHIP_GRAD2_MIN_WAVES 3   // waves per SIMD the register allocation must allow (168 VGPRs)
+#endif
 template <int D>
-__global__ __launch_bounds__(kGrad2Block, 3) void locus_grad2_kernel(const Grad2Params* __restrict__ Gp) {
+__global__ __launch_bounds__(kGrad2Block, TPHIP_GRAD2_MIN_WAVES) void locus_grad2_kernel(const Grad2Params* __restrict__ Gp) {
     const Grad2Params& G = *Gp;
     extern __shared__ double lds[];
     const int nn = G.nnodes;
@@ -214,6 +217,10 @@ __global__ __launch_bounds__(kGrad2Block, 3) void locus_grad2_kernel(const Grad2
 #pragma unroll
                         for (int i = 0; i < 4; ++i) msg[i] = fma(f, tpd[x * 4 + i], msg[i]);
                     }
+                    // the lanes beside it keep exactly what the fast path gives them (wave-independent results)
+                    const double2* row = (const double2*)(tp + (cd <= 4u ? cd : 0u) * 32);
+                    const double2 r0 = row[0], r1 = row[1];
+                    if (cd <= 4u) { msg[0] = r0.x; msg[1] = r0.y; msg[2] = r1.x; msg[3] = r1.y; }
                 }
             };
             auto tip_op = [&](int tab, int sh, bool fetch, int widx, auto set_tag) {

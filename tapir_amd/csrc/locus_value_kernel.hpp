@@ -96,8 +96,12 @@ __global__ __launch_bounds__(256) void value_pack_codes_kernel(const uint8_t* st
 
 typedef const double __attribute__((address_space(4)))* value_cptr;   // constant address space: wave-uniform reads become scalar loads
 
+#ifndef TPHIP_VALUE_MIN_WAVES
+#define TPHIP_VALUE_MIN_WAVES 4   // waves per SIMD the register allocation must allow: 128 VGPRs, 14 of the two-column
+                                 // variant's registers in scratch -- measured 10 % faster than 143 VGPRs at 3 waves (stage 1, 2000 x 1000 x 64)
+#endif
 template <int C, int D>
-__global__ __launch_bounds__(kLikBlock) void locus_value_kernel(ValueParams P) {
+__global__ __launch_bounds__(kLikBlock, TPHIP_VALUE_MIN_WAVES) void locus_value_kernel(ValueParams P) {
     extern __shared__ double lds[];
     double* TP = lds;                                           // [ntaxa][4 child states + a row of ones][4 parent states]
     uint32_t* msk = (uint32_t*)(TP + (size_t)P.ntaxa * kValueTipRow);   // [nwords][C][kLikBlock] 8 tip codes per word
@@ -219,6 +223,11 @@ __global__ __launch_bounds__(kLikBlock) void locus_value_kernel(ValueParams P) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) msg[c][i] = fma(f, tpd[x * 4 + i], msg[c][i]);
                     }
+                    // the lanes beside it keep EXACTLY what the fast path gives them (a gap is the row of ones, not the sum of
+                    // four floored rows): a column's value must not depend on which columns share its wave
+                    const double2* row = (const double2*)(tp + (cd[c] <= 4u ? cd[c] : 0u) * 32);
+                    const double2 r0 = row[0], r1 = row[1];
+                    if (cd[c] <= 4u) { msg[c][0] = r0.x; msg[c][1] = r0.y; msg[c][2] = r1.x; msg[c][3] = r1.y; }
                 }
             }
 #pragma unroll

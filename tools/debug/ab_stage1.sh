@@ -3,6 +3,6 @@
 shape=$1; shift
 for rep in 1 2; do
   for lib in "$@"; do
-    echo "$(basename $lib): $(TPHIP_LIB=$lib timeout -k 10 200 python tools/stage1_timing.py $shape 2>/dev/null | tail -1 | cut -c1-110)"
+    echo "$(basename $lib): $(TPHIP_LIB=$lib timeout -k 10 200 python tools/stage1_timing.py $shape cuda 2>/dev/null | tail -1 | cut -c1-110)"
   done
 done

@@ -1,6 +1,7 @@
 """Wall time of stage 1 through the ENGINE call (tphip_stage1_fit: optimisers as device kernels) on a synthetic batch,
 optionally beside the round-2 host optimiser (tapir_amd/stage1.py) on the same bytes.
-usage: python tools/stage1_timing.py LOCI COLS TAXA [compare] [reps=N]"""
+usage: python tools/stage1_timing.py LOCI COLS TAXA [compare] [reps=N] [cuda]   (cuda: simulate the batch on the GPU -- another
+random stream than the default CPU simulation, much faster to set up)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,9 +10,9 @@ from tapir_amd import engine, nexus, stage1, synth
 L, n, nt = (int(x) for x in sys.argv[1:4])
 compare = "compare" in sys.argv[4:]
 reps = max([int(a.split("=")[1]) for a in sys.argv[4:] if a.startswith("reps=")] + [2])
-d = synth.simulate(L, n, nt, 5)
+d = synth.simulate(L, n, nt, 5, device="cuda") if "cuda" in sys.argv[4:] else synth.simulate(L, n, nt, 5)
 pin = synth.plan_inputs(d["root"], d["names"])
-st = d["states"].numpy()
+st = d["states"].cpu().numpy()
 pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, d["locus_offsets"]))
 plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"], [1], [[0, 1]],
                    correction=pin["correction"])
