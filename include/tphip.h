@@ -65,7 +65,8 @@ enum {
 
 /* tphip_plan_desc.start_rule: where the per-site optimiser starts (HyPhy: siteRate = 1 before every Optimize, bf:1050) */
 enum {
-    TPHIP_START_AUTO = 0,      /* default: HyPhy's start on trees of fewer than 32 taxa, the parsimony start from 32 on    */
+    TPHIP_START_AUTO = 0,      /* default: HyPhy's start on trees of fewer than 32 taxa, the parsimony start from 32 on
+                                  (and with the rate-mixture extension, which HyPhy's script does not have)                */
     TPHIP_START_REFERENCE = 1, /* siteRate = 1 on every tree                                                            */
     TPHIP_START_PARSIMONY = 2  /* the column's parsimony rate on every tree (one evaluation fewer per column)           */
 };

@@ -260,15 +260,21 @@ def correct_branch_lengths_values(newick_text):
 # ctypes wrappers over tapir_oracle.c
 # --------------------------------------------------------------------------------------------------
 
-def site_rates(states, parent, blen, leaf_taxon, pi, exch, cat_rates=None, cat_weights=None, start_mode=0):
+AUTO_START_MIN_TAXA = 32   # = kFirstStepMinTaxa of the engine (csrc/site_rate_params.hpp): TPHIP_START_AUTO
+
+
+def site_rates(states, parent, blen, leaf_taxon, pi, exch, cat_rates=None, cat_weights=None, start_mode=None):
     """HyPhy stage 2 restatement for one locus. states: uint8 [ntaxa, ncols] masks.
     cat_rates / cat_weights: optional discrete rate mixture on top of the site rate (not in the reference).
-    start_mode: 0 = the optimiser the product uses (parsimony start, accelerated exits); 1 = reference-faithful:
+    start_mode: 0 = the product's optimiser from the parsimony start (accelerated exits); 1 = reference-faithful:
     every column starts at siteRate = 1 (models_and_rates.bf:1050), plain safeguarded Newton to 1e-12; 2 = the
-    product's step rule and exits started at siteRate = 1 (the engine's start_rule = 1).
+    product's step rule and exits started at siteRate = 1 (the engine's TPHIP_START_REFERENCE); None = what the engine
+    does by default (TPHIP_START_AUTO): 2 on trees of fewer than 32 taxa, 0 from 32 on.
     Returns dict(rate, subst, lnl, flag, nres, nevals)."""
     states = np.ascontiguousarray(states, dtype=np.uint8)
     ntaxa, ncols = states.shape
+    if start_mode is None:
+        start_mode = 0 if ntaxa >= AUTO_START_MIN_TAXA else 2
     parent = np.ascontiguousarray(parent, dtype=np.int32)
     blen = np.ascontiguousarray(blen, dtype=np.float64)
     leaf_taxon = np.ascontiguousarray(leaf_taxon, dtype=np.int32)

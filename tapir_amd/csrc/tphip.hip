@@ -223,8 +223,10 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
     p->T = d->T; p->n_t = d->n_t; p->n_i = d->n_i; p->integ_mode = d->integ_mode;
     p->threshold = d->threshold; p->round_decimals = d->round_decimals; p->correction = d->correction;
     // TPHIP_START_AUTO: HyPhy's own start where the parsimony start was ever seen to end on another local optimum (small trees)
-    p->start_rule = d->start_rule == TPHIP_START_AUTO ? (d->ntaxa >= kFirstStepMinTaxa ? TPHIP_START_PARSIMONY : TPHIP_START_REFERENCE)
-                                                      : d->start_rule;
+    // (the rate mixture is an extension without a HyPhy counterpart to start like: it keeps the parsimony start)
+    p->start_rule = d->start_rule == TPHIP_START_AUTO
+                        ? ((d->ntaxa >= kFirstStepMinTaxa || d->ncat > 1) ? TPHIP_START_PARSIMONY : TPHIP_START_REFERENCE)
+                        : d->start_rule;
     p->dedup_mode = d->pattern_dedup;
     p->ncat = cat.empty() ? 0 : d->ncat;
     std::string terr = build_tree_program(d->ntaxa, d->nnodes, d->parent, d->branch_len, d->leaf_taxon, &p->prog);

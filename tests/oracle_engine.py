@@ -33,7 +33,8 @@ class Plan:
                  correction=1.0, threshold=3, round_decimals=4, integ_mode=0, device=0, cat_rates=None, cat_weights=None,
                  start_rule=0):
         self.cat_rates, self.cat_weights = cat_rates, cat_weights
-        self.start_mode = 2 if start_rule else 0   # the engine's start_rule = 1 is the oracle's start_mode 2
+        # the engine's start_rule: 0 = TPHIP_START_AUTO (the oracle's default), 1 = REFERENCE (oracle mode 2), 2 = PARSIMONY (mode 0)
+        self.start_mode = {0: None, 1: 2, 2: 0}[int(start_rule)]
         self.ntaxa = ntaxa
         self.parent = np.asarray(parent, np.int32)
         self.blen = np.asarray(branch_len, np.float64)

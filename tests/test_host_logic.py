@@ -731,7 +731,7 @@ def test_rate_mixture_in_the_oracle_and_cli(tmp_path):
     d = synth.simulate(2, 60, 6, 4)
     pin = synth.plan_inputs(d["root"], d["names"])
     st = d["states"].numpy()[:, :60]
-    a = orc.site_rates(st, pin["parent"], pin["blen"], pin["leaf"], d["pi"][0], d["exch"][0])
+    a = orc.site_rates(st, pin["parent"], pin["blen"], pin["leaf"], d["pi"][0], d["exch"][0], start_mode=0)   # the mixture's start
     b = orc.site_rates(st, pin["parent"], pin["blen"], pin["leaf"], d["pi"][0], d["exch"][0], [1.0, 1.0, 1.0], [0.2, 0.3, 0.5])
     ok = a["flag"] == 0
     assert np.array_equal(a["flag"], b["flag"]) and np.abs(a["rate"] - b["rate"])[ok].max() < 1e-12
