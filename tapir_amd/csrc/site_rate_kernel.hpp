@@ -622,6 +622,34 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         const int64_t pbeg = P.work_prefix[lo_l];
         g0 = pbeg + (int64_t)j * count / ns;
         g1 = pbeg + (int64_t)(j + 1) * count / ns;
+        if (P.work_cols2) {
+            // Slow columns first (classify_kernel marked them in the lnl slot): a stable partition of this wave's slice of
+            // the work list into the scratch list, two passes of 64 entries at a time.  A wave lasts until its slowest lane
+            // is done; with ~5 columns per lane, a 15-evaluation column handed out in the last round doubles that.
+            const int32_t* __restrict__ src = P.work_cols + P.locus_offsets[lo_l];
+            int32_t* __restrict__ dst = P.work_cols2 + P.locus_offsets[lo_l];
+            const int b = (int)(g0 - pbeg), e = (int)(g1 - pbeg);
+            int nh = 0;
+            for (int i = b; i < e; i += kSiteBlock) {
+                const bool in = i + lane < e;
+                const int32_t c = src[in ? i + lane : b];
+                nh += __popcll(__ballot(in && P.lnl[c] != 0.0));
+            }
+            int ph = b, pe = b + nh;
+            for (int i = b; i < e; i += kSiteBlock) {
+                const bool in = i + lane < e;
+                const int32_t c = src[in ? i + lane : b];
+                const bool hard = in && P.lnl[c] != 0.0;
+                const unsigned long long mh = __ballot(hard), me = __ballot(in && !hard);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (hard) dst[ph + __popcll(mh & below)] = c;
+                else if (in) dst[pe + __popcll(me & below)] = c;
+                ph += __popcll(mh);
+                pe += __popcll(me);
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
     }
     unsigned evals = 0;
     int64_t gpos = g0;
@@ -636,7 +664,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         build_tip_table(M, wtab, lane);
         const ModelRegs R = load_model(M, mtab, lane);
         const double kappa = mtab[31];
-        const int32_t* __restrict__ work = P.work_cols + P.locus_offsets[locus];
+        const int32_t* __restrict__ work = ((!P.persistent && P.work_cols2) ? (const int32_t*)P.work_cols2 : P.work_cols) + P.locus_offsets[locus];
 
         int next = begin + kSiteBlock;  // wave-uniform: first work index not yet handed to a lane
         bool done = (begin + lane >= end);

@@ -52,6 +52,8 @@ struct SiteParams {
     const uint32_t* packed;        // [nwords][ncols_total] 8 tip masks per word, tips in program order (classify_kernel)
     int32_t nwords;                // ceil(ntips / 8)
     const int32_t* work_cols;      // [ncols_total] compacted column ids, per locus at locus_offsets[l]
+    int32_t* work_cols2;           // [ncols_total] scratch of the same shape, or null: in the small-batch mode every wave
+                                   // rewrites its slice of the list there with the columns predicted to be slow first
     const int32_t* work_count;     // [nloci]
     const int64_t* work_prefix;    // [nloci+1] exclusive scan of work_count (scan_counts_kernel)
     const int64_t* slice_prefix;   // [nloci+1] exclusive scan of the per-locus slice counts (non-persistent mode)

@@ -515,6 +515,9 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
     // workspace layout
     size_t off = 0;
     p->ws_work_cols = off; off = align_up(off + sizeof(int32_t) * (size_t)ncols, 256);
+    if (!p->site_persistent && !getenv("TPHIP_SITE_NO_REORDER")) {   // small batches: slow-columns-first copy of the work list
+        p->ws_work_cols2 = off; off = align_up(off + sizeof(int32_t) * (size_t)ncols, 256);
+    }
     p->ws_work_count = off; off = align_up(off + sizeof(int32_t) * (size_t)d->nloci, 256);
     p->ws_work_prefix = off; off = align_up(off + sizeof(int64_t) * ((size_t)d->nloci + 1), 256);
     p->ws_slice_prefix = off; off = align_up(off + sizeof(int64_t) * ((size_t)d->nloci + 1), 256);
@@ -683,6 +686,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.chunk_cols = p->site_chunk_cols;
     S.packed = (const uint32_t*)((char*)ws + p->ws_packed); S.nwords = p->nwords;
     S.work_cols = work_cols; S.work_count = work_count;
+    S.work_cols2 = (!p->site_persistent && p->ws_work_cols2) ? (int32_t*)((char*)ws + p->ws_work_cols2) : nullptr;
     S.work_prefix = (const int64_t*)((char*)ws + p->ws_work_prefix); S.nloci = p->nloci;
     S.slice_prefix = (const int64_t*)((char*)ws + p->ws_slice_prefix);
     S.rate = d_rate; S.subst = d_subst; S.lnl = d_lnl; S.flag = d_flag; S.eval_counter = p->d_evals.p;
@@ -1347,7 +1351,7 @@ int tphip_eval_columns_dev(tphip_plan* p, const uint8_t* d_s, const double* d_u,
     E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
     E.S.chunk_cols = p->site_chunk_cols;
     E.S.packed = nullptr; E.S.nwords = 0;
-    E.S.work_cols = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
+    E.S.work_cols = nullptr; E.S.work_cols2 = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
     E.S.flag = nullptr; E.S.eval_counter = nullptr; E.S.spill = nullptr; E.S.lds_depth = p->prog.stack_depth;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);

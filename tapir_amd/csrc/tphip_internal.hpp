@@ -141,7 +141,7 @@ struct tphip_plan {
     DevBuf<int32_t> d_site_chunk_locus, d_site_chunk_index, d_pi_chunk_locus, d_pi_chunk_index, d_times, d_intervals;
     DevBuf<unsigned long long> d_evals;
     // workspace layout (bytes)
-    size_t ws_work_cols = 0, ws_work_count = 0, ws_work_prefix = 0, ws_slice_prefix = 0, ws_partial = 0, ws_packed = 0, ws_total = 0;
+    size_t ws_work_cols2 = 0, ws_work_cols = 0, ws_work_count = 0, ws_work_prefix = 0, ws_slice_prefix = 0, ws_partial = 0, ws_packed = 0, ws_total = 0;
     size_t ws_hash = 0, ws_dup_of = 0, ws_tab_key = 0, ws_tab_val = 0, ws_dedup_on = 0;   // site-pattern de-duplication
     int32_t dedup_mode = 0;   // DEDUP_AUTO (pattern_kernels.hpp)
     int32_t num_cus = 256;
