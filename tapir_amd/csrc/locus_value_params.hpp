@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 #include "gtr_model.hpp"
+#include "tree_program.hpp"
 
 namespace tphip {
 
@@ -39,6 +41,57 @@ struct ValueParams {
     double* out;                   // [ncand * nsplit]
     int32_t nsplit;
 };
+
+// The value kernels' fused op stream from the plain tree program (host): TIP_SET + TIP_MUL -> CHERRY (whatever the branch
+// lengths: the messages are table rows), PUSH carried by the TIP_SET / CHERRY that follows it, POP_MUL by the BRANCH it
+// follows; closed by two kValueOpEnd records.  tip_node[taxon] = tree node of the taxon's tip.  False: the program has a
+// shape the stream cannot express (the eigenbasis kernels run instead).
+inline bool build_value_program(const TreeProgram& prog, int32_t ntaxa, int32_t nnodes, std::vector<int4>* vops_out,
+                                std::vector<int32_t>* tip_node_out) {
+    const auto& ops = prog.ops;
+    const auto& node = prog.op_node;
+    std::vector<int4>& vops = *vops_out;
+    std::vector<int32_t>& tip_node = *tip_node_out;
+    vops.clear();
+    tip_node.assign(ntaxa, -1);
+    int32_t pending = 0, tip = 0;
+    bool ok = nnodes < 65536 && (int64_t)ntaxa * kValueTipRow * 8 < (1 << 30);
+    auto tip_bits = [&](int shift_pos, int fetch_pos) { return ((4 * (tip & 7)) << shift_pos) | (((tip & 7) == 0 ? 1 : 0) << fetch_pos); };
+    for (size_t i = 0; i < ops.size() && ok; ++i) {
+        const int32_t code = ops[i].code;
+        const bool has_next = i + 1 < ops.size();
+        if (code == OP_PUSH) {
+            if (!(has_next && ops[i + 1].code == OP_TIP_SET) || pending) ok = false;   // (a PUSH is always followed by a TIP_SET)
+            pending = OP_PUSH_BEFORE;
+        } else if (code == OP_TIP_SET && has_next && ops[i + 1].code == OP_TIP_MUL) {
+            int32_t x = OP_CHERRY | pending | tip_bits(12, 17);
+            const int32_t wa = tip >> 3;
+            ++tip;
+            x |= tip_bits(20, 25);
+            const int32_t wb = tip >> 3;
+            ++tip;
+            vops.push_back(make_int4(x, ops[i].taxon * kValueTipRow * 8, ops[i + 1].taxon * kValueTipRow * 8, wa | (wb << 16)));
+            tip_node[ops[i].taxon] = node[i];
+            tip_node[ops[i + 1].taxon] = node[i + 1];
+            pending = 0;
+            ++i;
+        } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
+            vops.push_back(make_int4(code | pending | tip_bits(12, 17), ops[i].taxon * kValueTipRow * 8, 0, tip >> 3));
+            tip_node[ops[i].taxon] = node[i];
+            ++tip;
+            pending = 0;
+        } else if (code == OP_BRANCH) {
+            const bool pop = has_next && ops[i + 1].code == OP_POP_MUL;
+            vops.push_back(make_int4(OP_BRANCH | (pop ? OP_POP_AFTER : 0), node[i] * 128, 0, 0));
+            if (pop) ++i;
+        } else {
+            ok = false;   // a POP_MUL that does not follow a BRANCH
+        }
+    }
+    vops.push_back(make_int4(kValueOpEnd, 0, 0, 0));
+    vops.push_back(make_int4(kValueOpEnd, 0, 0, 0));
+    return ok;
+}
 
 constexpr int kValueMaxDepth = 5;   // deepest register stack instantiated (a Sethi-Ullman-ordered tree of 2^(D+1) tips needs D)
 

@@ -296,49 +296,11 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
         e = p->d_lik_ops.upload(lops);
     }
     if (e == hipSuccess) {
-        // locus_value_kernel's stream (layout: locus_value_params.hpp): TIP_SET + TIP_MUL -> CHERRY (whatever the branch
-        // lengths: the messages are table rows), PUSH carried by the TIP_SET / CHERRY that follows it, POP_MUL by the
-        // BRANCH it follows
+        // locus_value_kernel's stream (build_value_program, locus_value_params.hpp)
         const auto& ops = p->prog.ops;
-        const auto& node = p->prog.op_node;
         std::vector<int4> vops;
-        std::vector<int32_t> tip_node(d->ntaxa, -1);
-        int32_t pending = 0, tip = 0;
-        bool ok = d->nnodes < 65536 && d->ntaxa * kValueTipRow * 8 < (1 << 30);
-        auto tip_bits = [&](int shift_pos, int fetch_pos) { return ((4 * (tip & 7)) << shift_pos) | (((tip & 7) == 0 ? 1 : 0) << fetch_pos); };
-        for (size_t i = 0; i < ops.size() && ok; ++i) {
-            const int32_t code = ops[i].code;
-            const bool has_next = i + 1 < ops.size();
-            if (code == OP_PUSH) {
-                if (!(has_next && ops[i + 1].code == OP_TIP_SET) || pending) ok = false;   // (a PUSH is always followed by a TIP_SET)
-                pending = OP_PUSH_BEFORE;
-            } else if (code == OP_TIP_SET && has_next && ops[i + 1].code == OP_TIP_MUL) {
-                int32_t x = OP_CHERRY | pending | tip_bits(12, 17);
-                const int32_t wa = tip >> 3;
-                ++tip;
-                x |= tip_bits(20, 25);
-                const int32_t wb = tip >> 3;
-                ++tip;
-                vops.push_back(make_int4(x, ops[i].taxon * kValueTipRow * 8, ops[i + 1].taxon * kValueTipRow * 8, wa | (wb << 16)));
-                tip_node[ops[i].taxon] = node[i];
-                tip_node[ops[i + 1].taxon] = node[i + 1];
-                pending = 0;
-                ++i;
-            } else if (code == OP_TIP_SET || code == OP_TIP_MUL) {
-                vops.push_back(make_int4(code | pending | tip_bits(12, 17), ops[i].taxon * kValueTipRow * 8, 0, tip >> 3));
-                tip_node[ops[i].taxon] = node[i];
-                ++tip;
-                pending = 0;
-            } else if (code == OP_BRANCH) {
-                const bool pop = has_next && ops[i + 1].code == OP_POP_MUL;
-                vops.push_back(make_int4(OP_BRANCH | (pop ? OP_POP_AFTER : 0), node[i] * 128, 0, 0));
-                if (pop) ++i;
-            } else {
-                ok = false;   // a POP_MUL that does not follow a BRANCH
-            }
-        }
-        vops.push_back(make_int4(kValueOpEnd, 0, 0, 0));
-        vops.push_back(make_int4(kValueOpEnd, 0, 0, 0));
+        std::vector<int32_t> tip_node;
+        const bool ok = build_value_program(p->prog, d->ntaxa, d->nnodes, &vops, &tip_node);
         if (ok) e = p->d_value_tip_node.upload(tip_node);
         p->value_nops = ok ? (int32_t)vops.size() : 0;
         if (ok && e == hipSuccess) e = p->d_value_ops.upload(vops);
