@@ -277,6 +277,54 @@ def test_stage1_degenerate_loci_stay_finite():
     assert np.all(np.isfinite(e2)) and e2[0, 1] == 1.0
 
 
+def test_stage1_engine_call_on_degenerate_and_large_inputs():
+    """tphip_stage1_fit with empirical frequencies and device-side patterns where the data give little to go on: an empty
+    locus, a locus of gaps only (no cell: frequencies fall back to 1/4), an invariant locus (one base only: its frequency
+    goes to ~1 and the others to the floor) next to an informative one -- everything stays finite, AG = 1, weights sum to 1,
+    and the informative locus gets the estimates it gets alone.  And a 256-taxon tree (the C5 shape's tree size: deeper
+    register / adjoint stacks, 32 packed words per column): the engine agrees with the host second opinion."""
+    engine = _engine()
+    from tapir_amd import nexus, stage1, synth
+    d = synth.simulate(1, 300, 6, 3)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    good = d["states"].numpy()
+    gaps = np.full((6, 50), 15, np.uint8)
+    same = np.full((6, 80), 2, np.uint8)
+    st = np.ascontiguousarray(np.concatenate([gaps, same, good], axis=1))
+    off = np.array([0, 0, 50, 130, 430])
+    mk = lambda o, L: engine.Plan(6, pin["parent"], pin["blen"], pin["leaf"], o, np.full((L, 4), 0.25), np.ones((L, 6)), pin["T"],  # noqa: E731
+                                  [1], [[0, 1]], correction=pin["correction"])
+    plan = mk(off, 4)
+    out = plan.stage1_fit(st, compress_patterns=True, empirical_pi=True)
+    plan.close()
+    assert np.all(np.isfinite(out["exch"])) and np.all(out["exch"][:, 1] == 1.0) and np.all(np.isfinite(out["lnl"]))
+    assert np.allclose(out["weights"].sum(1), 1.0) and np.all(out["exch"] > 5e-4) and np.all(out["exch"] < 2e4)
+    assert np.allclose(out["pi"][0], 0.25) and np.allclose(out["pi"][1], 0.25)
+    assert out["pi"][2, 1] > 0.999 and np.allclose(out["pi"].sum(1), 1.0, atol=1e-9)
+    assert np.allclose(out["exch"][0], 1.0) and np.allclose(out["exch"][1], 1.0)
+    alone = mk(np.array([0, 300]), 1)
+    ref = alone.stage1_fit(good, compress_patterns=True, empirical_pi=True)
+    alone.close()
+    assert np.max(np.abs(ref["pi"][0] - out["pi"][3])) < 1e-15
+    assert np.max(np.abs(ref["exch"][0] - out["exch"][3]) / out["exch"][3]) < 1e-6
+    # 256 taxa
+    L, n, nt = 3, 600, 256
+    d = synth.simulate(L, n, nt, 77)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, d["locus_offsets"]))
+    plan = engine.Plan(nt, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"], [1], [[0, 1]],
+                       correction=pin["correction"])
+    a = plan.stage1_fit(st)
+    host = stage1.Stage1(plan, st, pi, pin["parent"], np.asarray(pin["blen"]))
+    b = host.run()
+    host.close()
+    plan.close()
+    assert np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-3
+    assert np.all(a["lnl"][:, 0] >= b["lnl"][:, 0] - 1e-3)
+    assert np.max(np.abs(a["weights"] - b["weights"])) < 2e-3   # (two optimisers on 510 branch lengths: the stash differs within tolerance)
+
+
 def test_stage1_fullsize_properties():
     """Stage 1 at the C3 shape (50 000 columns x 64 taxa per locus; 4 loci), through size-independent properties:
     the general model's point is stationary (gradient kernel at the returned point), nesting holds (no constrained
