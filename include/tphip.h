@@ -308,6 +308,12 @@ int tphip_pi_tables(tphip_plan *plan, const double *rates, const int32_t *nres, 
 int tphip_corrected_rates(tphip_plan *plan, const double *rates, const int32_t *nres, double *out);
 int tphip_run_fused(tphip_plan *plan, const uint8_t *states, double *rate, double *subst, double *lnl,
                     uint8_t *flag, int32_t *nres, double *tables);
+/* tphip_run_fused on a column range of a bigger taxon-major array: `states` points at the range's first column of taxon 0,
+ * consecutive taxon rows are row_pitch bytes apart (0 = the plan's column count).  The upload is one 2-D copy; from pinned
+ * memory no host copy is made.  With tphip_stage1_fit (opts.row_pitch) and tphip_plan_set_models this lets a caller stream a
+ * big batch block by block -- stage 1, the per-site loop and PI of block k while the host still writes block k - 1's files. */
+int tphip_run_fused_pitched(tphip_plan *plan, const uint8_t *states, int64_t row_pitch, double *rate, double *subst,
+                            double *lnl, uint8_t *flag, int32_t *nres, double *tables);
 int tphip_townsend_pi_dense(int32_t device, const double *rates, int64_t n, const double *times, int32_t n_times,
                             double *out);
 int tphip_quad_townsend(int32_t device, const double *rates, int64_t n, double a, double b, int32_t integ_mode,

@@ -210,6 +210,32 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
         conn.close()
         LAST_TIMINGS["sqlite"] = time.perf_counter() - t_db
 
+    class _TableSink:
+        """sqlite rows block by block, in file order, while later blocks are still being computed (pipeline._run_streamed)"""
+
+        def __init__(self):
+            self.conn = self.c = None
+            self.seconds = 0.0
+
+        def add(self, names, tables):
+            import time
+            t0 = time.perf_counter()
+            if self.conn is None:
+                self.conn, self.c = db.create_probe_db(db_name)
+            db.insert_tables(self.conn, self.c, names, tables, T, args.times, args.intervals)
+            self.seconds += time.perf_counter() - t0
+
+        def close(self):
+            import time
+            t0 = time.perf_counter()
+            if self.conn is None:
+                self.conn, self.c = db.create_probe_db(db_name)
+            self.conn.commit()
+            self.c.close()
+            self.conn.close()
+            self.seconds += time.perf_counter() - t0
+            LAST_TIMINGS["sqlite"] = self.seconds
+
     if not args.site_rates:
         if rank == 0:
             print("\nEstimating site rates and PI for files:")
@@ -228,7 +254,8 @@ def _main(args, rank, world, on_gpu, engine_mod, pool):
                                                engine_mod=engine_mod, progress=progress, pool=pool,
                                                cat_rates=cat_rates, cat_weights=cat_weights,
                                                start_rule=1 if args.reference_start else 0,
-                                               during_write=store if world == 1 else None)
+                                               during_write=store if world == 1 else None,
+                                               table_sink=_TableSink() if world == 1 else None)
             tables = out["final_tables"]
             stored = bool(out.get("during_write_done"))
             sqlite_seconds = LAST_TIMINGS.get("sqlite")

@@ -1197,8 +1197,11 @@ static int host_wait(tphip_plan* p) {
 constexpr int64_t kHostSplitMinColumns = (int64_t)1 << 21;   // below this a pass is too short for the pipeline to pay
 
 static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in, const int32_t* nres_in, double* rate,
-                    double* subst, double* lnl, uint8_t* flag, int32_t* nres, double* tables, bool do_site, bool do_pi) {
+                    double* subst, double* lnl, uint8_t* flag, int32_t* nres, double* tables, bool do_site, bool do_pi,
+                    size_t row_pitch = 0) {
     if (!p) return fail(TPHIP_ERR_INVALID, "null plan");
+    const size_t pitch = row_pitch ? row_pitch : (size_t)p->ncols;   // bytes between taxon rows of `states` at the caller
+    if (pitch < (size_t)p->ncols) return fail(TPHIP_ERR_INVALID, "row_pitch smaller than the plan's column count");
     // Big batches from pinned host memory: locus groups in a pipeline -- the upload of group k + 1 (and the download of group
     // k - 1) run while group k computes.  Results do not depend on how a batch is cut (per-column results depend on the
     // column and its locus' model only, a locus' PI row on its own columns in a fixed order).
@@ -1208,7 +1211,7 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
                        is_pinned(nres) && (!do_pi || (tables && is_pinned(tables)));
     if (!split) {
         // always drain: a failed enqueue may already have copies in flight that touch the caller's buffers
-        const int rc = host_enqueue(p, states, (size_t)p->ncols, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables,
+        const int rc = host_enqueue(p, states, pitch, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables,
                                     do_site, do_pi);
         const int rw = host_wait(p);
         return rc ? rc : rw;
@@ -1216,7 +1219,7 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
     int rc = make_parts(p);
     if (rc) return rc;
     if (p->parts.empty()) {   // the batch does not cut into groups with columns
-        rc = host_enqueue(p, states, (size_t)p->ncols, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables, do_site, do_pi);
+        rc = host_enqueue(p, states, pitch, nullptr, rates_in, nres_in, rate, subst, lnl, flag, nres, tables, do_site, do_pi);
         const int rw = host_wait(p);
         return rc ? rc : rw;
     }
@@ -1226,7 +1229,7 @@ static int host_run(tphip_plan* p, const uint8_t* states, const double* rates_in
     for (size_t k = 0; k < p->parts.size(); ++k) {
         tphip_plan* q = p->parts[k];
         const int64_t l0 = p->part_locus[k], c0 = p->h_offsets[l0];
-        rc = host_enqueue(q, states + c0, (size_t)p->ncols, after, nullptr, nullptr, rate + c0, subst + c0, lnl + c0, flag + c0,
+        rc = host_enqueue(q, states + c0, pitch, after, nullptr, nullptr, rate + c0, subst + c0, lnl + c0, flag + c0,
                           nres + c0, do_pi ? tables + (size_t)l0 * W : nullptr, true, do_pi);
         if (rc) break;
         after = q->hostbuf->ev_in;
@@ -1262,6 +1265,12 @@ int tphip_pi_tables(tphip_plan* p, const double* rates, const int32_t* nres, dou
 int tphip_run_fused(tphip_plan* p, const uint8_t* states, double* rate, double* subst, double* lnl, uint8_t* flag,
                     int32_t* nres, double* tables) {
     return host_run(p, states, nullptr, nullptr, rate, subst, lnl, flag, nres, tables, true, true);
+}
+
+int tphip_run_fused_pitched(tphip_plan* p, const uint8_t* states, int64_t row_pitch, double* rate, double* subst, double* lnl,
+                            uint8_t* flag, int32_t* nres, double* tables) {
+    if (row_pitch < 0) return fail(TPHIP_ERR_INVALID, "negative row_pitch");
+    return host_run(p, states, nullptr, nullptr, rate, subst, lnl, flag, nres, tables, true, true, (size_t)row_pitch);
 }
 
 int tphip_townsend_pi_dense(int32_t device, const double* rates, int64_t n, const double* times, int32_t n_times, double* out) {

@@ -73,6 +73,7 @@ SYMBOLS = [
     ("tphip_site_rates", ctypes.c_int, [_vp] * 7),
     ("tphip_pi_tables", ctypes.c_int, [_vp] * 4),
     ("tphip_run_fused", ctypes.c_int, [_vp] * 8),
+    ("tphip_run_fused_pitched", ctypes.c_int, [_vp, _vp, _i64] + [_vp] * 6),
     ("tphip_townsend_pi_dense", ctypes.c_int, [_i32, _vp, _i64, _vp, _i32, _vp]),
     ("tphip_quad_townsend", ctypes.c_int, [_i32, _vp, _i64, _f64, _f64, _i32, _vp, _vp]),
     ("tphip_state_histogram", ctypes.c_int, [_i32, _vp, _i64, _i32, _vp, _i64, _vp]),
@@ -292,6 +293,22 @@ class Plan:
                                          out["lnl"].ctypes.data, out["flag"].ctypes.data, out["nres"].ctypes.data,
                                          out["tables"].ctypes.data))
         return out
+
+    def run_fused_into(self, states, out, col0=0, locus0=0):
+        """tphip_run_fused_pitched: `states` may be a column range of a bigger C-contiguous [ntaxa, N] array (a view
+        states[:, a:b]); the results go into the caller's arrays `out` (rate, subst, lnl, flag, nres: 1-D over the big batch;
+        tables [loci, W]) at column `col0` and locus `locus0` -- how pipeline.py streams a batch block by block."""
+        if states.dtype != np.uint8 or states.ndim != 2 or states.strides[1] != 1:
+            states = _np(states, np.uint8)
+        assert states.shape == (self.ntaxa, self.ncols), (states.shape, self.ntaxa, self.ncols)
+        pitch = int(states.strides[0]) if self.ntaxa > 1 else self.ncols
+        a, b = int(col0), int(col0) + self.ncols
+        views = [out[k][a:b] for k in ("rate", "subst", "lnl", "flag", "nres")] + [out["tables"][locus0:locus0 + self.nloci]]
+        for v, dt in zip(views, (np.float64, np.float64, np.float64, np.uint8, np.int32, np.float64)):
+            if v.dtype != dt or not v.flags["C_CONTIGUOUS"]:
+                raise TphipError("output arrays must be C-contiguous with the documented dtypes")
+        assert len(views[0]) == self.ncols and views[5].shape == (self.nloci, self.width)
+        _check(self._lib.tphip_run_fused_pitched(self._h, states.ctypes.data, pitch, *[v.ctypes.data for v in views]))
 
     def eval_columns(self, states, u):
         """Diagnostic: (f, g, h) = log L and its u-derivatives for every column at u[ncols]."""

@@ -108,6 +108,10 @@ class HostPool:
                 pass
         return states, offsets
 
+    def write_rates_async(self, jobs):
+        """Hand the jobs to the workers and return at once; .get() on the result waits (and raises what a worker raised)."""
+        return self._pool.map_async(_write_job, jobs, chunksize=max(1, len(jobs) // (8 * self.workers)))
+
     def write_rates(self, jobs, progress=None):
         for _ in self._pool.imap_unordered(_write_job, jobs, chunksize=max(1, len(jobs) // (8 * self.workers))):
             if progress:
@@ -313,7 +317,7 @@ def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, bl
     from . import stage1
     offsets = np.asarray(offsets, dtype=np.int64)
     L = len(offsets) - 1
-    step = int(block_loci or STAGE1_BLOCK_LOCI)
+    step = int(block_loci or _block_sizes()[0])
     out = np.empty((L, 6))
     pi_used = np.empty((L, 4))
     if pi is not None:
@@ -350,10 +354,126 @@ def model_averaged_exchangeabilities(eng, states, offsets, pi, ntaxa, parent, bl
     return (out, pi_used) if return_pi else out
 
 
+STREAM_BLOCK_LOCI = 8192   # loci per block of the streamed run (_run_streamed)
+
+
+def _block_sizes():
+    """(stage-1 block, stream block) in loci; TPHIP_STREAM_BLOCK=n sets both to n (tests: a streamed and an unstreamed run of
+    the same small batch then fit the same loci together and must write the same bytes)."""
+    env = os.environ.get("TPHIP_STREAM_BLOCK")
+    if env:
+        n = max(1, int(env))
+        return n, n
+    return STAGE1_BLOCK_LOCI, STREAM_BLOCK_LOCI
+
+
+def _run_streamed(eng, states, offsets, alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
+                  pi, output_dir, device, integ_mode, round_decimals, extra, pool, progress, table_sink, timings, lap):
+    """The whole pipeline block by block, host and device working at the same time.
+
+    Block k of the loci: stage 1 (one tphip_stage1_fit call on the block's column range of the pinned batch array), its
+    estimates into the same plan (tphip_plan_set_models), the per-site loop and the PI tables (tphip_run_fused_pitched) --
+    and while the GPU does that for block k + 1, the pool's workers format block k's `.rates` files from a shared array and
+    a second thread of this process inserts block k's PI rows into sqlite (`table_sink`).  At C4 scale the GPU needs ~8 s for
+    the 50 000 loci and the host ~8 s for their 12 GB of text and 5.4 M rows: one after the other that is the sum, here close
+    to the larger.  Results are those of the unstreamed run (loci are independent; every array is filled at the same places)."""
+    import tempfile
+    import time
+    L = len(alignments)
+    total = int(offsets[-1])
+    ntaxa = len(leaf_names)
+    W = T + len(times) + 2 * len(intervals)
+    new = getattr(eng, "pinned_empty", None) or np.empty
+    out = dict(rate=new(total, np.float64), subst=new(total, np.float64), lnl=new(total, np.float64), flag=new(total, np.uint8),
+               nres=new(total, np.int32), tables=new((L, W), np.float64))
+    exch_all, pi_all = np.empty((L, 6)), np.empty((L, 4))
+    per_locus = [None] * L
+    fd, shared = tempfile.mkstemp(prefix="tapir_amd_", suffix=".f64", dir=_shared_dir(32 * max(total, 1)))
+    os.close(fd)
+    pending = []
+    sink_thread = None
+    if table_sink is not None:
+        import queue
+        import threading
+        q = queue.Queue()
+        err = []
+
+        def drain():
+            try:
+                while True:
+                    item = q.get()
+                    if item is None:
+                        table_sink.close()   # (sqlite objects live and die on the thread that made them)
+                        return
+                    table_sink.add(*item)
+            except BaseException as exc:   # handed to the main thread at the end
+                err.append(exc)
+        sink_thread = threading.Thread(target=drain, name="tapir_amd-sqlite")
+        sink_thread.start()
+    try:
+        arr = np.memmap(shared, dtype=np.float64, mode="w+", shape=(4, max(total, 1)))
+        step = _block_sizes()[1]
+        for l0 in range(0, L, step):
+            l1 = min(L, l0 + step)
+            a, b = int(offsets[l0]), int(offsets[l1])
+            cols = states[:, a:b]
+            blk_pi = np.full((l1 - l0, 4), 0.25) if pi is None else pi[l0:l1]
+            plan = eng.Plan(ntaxa, parent, blen, leaf, offsets[l0:l1 + 1] - a, blk_pi, np.ones((l1 - l0, 6)), T, times, intervals,
+                            correction=correction, threshold=threshold, round_decimals=round_decimals, integ_mode=integ_mode,
+                            device=device, **extra)
+            try:
+                res = plan.stage1_fit(cols, details=False, compress_patterns=True, empirical_pi=pi is None)
+                lap("stage1_model_averaging")
+                exch_all[l0:l1], pi_all[l0:l1] = res["exch"], res["pi"]
+                plan.set_models(exch=res["exch"])
+                plan.run_fused_into(cols, out, col0=a, locus0=l0)
+                lap("site_rates_and_pi_incl_pcie")
+            finally:
+                plan.close()
+            rate4 = compute.round_like_hyphy(out["rate"][a:b], round_decimals) if round_decimals >= 0 else out["rate"][a:b]
+            corrected = rate4 / correction
+            culled = np.where(out["nres"][a:b] >= threshold, corrected, np.nan)
+            for l in range(l0, l1):
+                per_locus[l] = culled[offsets[l] - a:offsets[l + 1] - a]
+            arr[0, a:b], arr[1, a:b], arr[2, a:b], arr[3, a:b] = out["subst"][a:b], rate4, out["lnl"][a:b], corrected
+            lap("round_correct_cull")
+            jobs = [(os.path.join(output_dir, os.path.basename(alignments[l]) + ".rates"), shared, max(total, 1), int(offsets[l]),
+                     int(offsets[l + 1]), pi_all[l], exch_all[l]) for l in range(l0, l1)]
+            pending.append(pool.write_rates_async(jobs))
+            if sink_thread is not None:
+                q.put((alignments[l0:l1], out["tables"][l0:l1].copy()))
+        t_w = time.perf_counter()
+        for res in pending:
+            for _ in res.get():
+                if progress:
+                    progress()
+        del arr
+        lap("write_rates_files")
+        if sink_thread is not None:
+            q.put(None)
+            sink_thread.join()
+            if err:
+                raise err[0]
+            out["during_write_done"] = True
+            lap("sqlite_tail")
+    finally:
+        if sink_thread is not None and sink_thread.is_alive():
+            q.put(None)
+            sink_thread.join()
+        try:
+            os.unlink(shared)
+        except OSError:
+            pass
+    out["timings"] = timings
+    out["final_tables"] = out["tables"]
+    out["streamed_blocks"] = (L + step - 1) // step
+    return _tuples(alignments, per_locus, out["tables"], T, times, intervals), out
+
+
 def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction, threshold,
                    exch, pi=None, subsets=None, output_dir=None, device=0, integ_mode=0, round_decimals=4,
                    engine_mod=None, progress=None, pool=None, cat_rates=None, cat_weights=None, start_rule=0,
-                   during_write=None):
+                   during_write=None, table_sink=None):
     """Site rates + PI for a list of NEXUS alignments.  Returns a list of worker()-shaped tuples
     (alignment, rates, mean_rate, None, pi_net, pi_times, pi_epochs) in the order of `alignments`.
 
@@ -382,6 +502,18 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     states, offsets = load_alignments(alignments, leaf_names, pool, alloc=pinned)
     lap("parse_nexus")
     L = len(alignments)
+    extra = {} if cat_rates is None or len(cat_rates) <= 1 else dict(cat_rates=cat_rates, cat_weights=cat_weights)
+    if start_rule:   # every column starts at siteRate = 1 as in HyPhy (bf:1050) instead of at its parsimony rate
+        extra["start_rule"] = int(start_rule)
+    need_subset = any(os.path.basename(a) in subsets for a in alignments)
+    if (exch is None and pool is not None and hasattr(pool, "write_rates_async") and output_dir is not None and not need_subset and
+            L > _block_sizes()[1] and hasattr(eng, "Plan") and hasattr(eng.Plan, "run_fused_into") and
+            _shared_dir(32 * max(int(offsets[-1]), 1)) is not None and os.environ.get("TPHIP_NO_STREAM") is None):
+        if pi is not None:
+            pi = np.asarray(pi, dtype=np.float64).reshape(L, 4)
+        return _run_streamed(eng, states, offsets, alignments, leaf_names, parent, blen, leaf, T, times, intervals, correction,
+                             threshold, pi, output_dir, device, integ_mode, round_decimals, extra, pool, progress, table_sink,
+                             timings, lap)
     if pi is None and exch is not None:
         hist = eng.state_histogram(states, offsets, device=device)
         pi = nexus.base_frequencies_from_histogram(hist)
@@ -394,14 +526,10 @@ def run_alignments(alignments, leaf_names, parent, blen, leaf, T, times, interva
     exch = np.asarray(exch, dtype=np.float64)
     if exch.ndim == 1:
         exch = np.tile(exch, (L, 1))
-    extra = {} if cat_rates is None or len(cat_rates) <= 1 else dict(cat_rates=cat_rates, cat_weights=cat_weights)
-    if start_rule:   # every column starts at siteRate = 1 as in HyPhy (bf:1050) instead of at its parsimony rate
-        extra["start_rule"] = int(start_rule)
     plan = eng.Plan(len(leaf_names), parent, blen, leaf, offsets, pi, exch, T, times, intervals,
                     correction=correction, threshold=threshold, round_decimals=round_decimals,
                     integ_mode=integ_mode, device=device, **extra)
     try:
-        need_subset = any(os.path.basename(a) in subsets for a in alignments)
         if need_subset:
             out = plan.site_rates(states)
         else:

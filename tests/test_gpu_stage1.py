@@ -94,6 +94,44 @@ def test_cli_default_model_averaging_on_gpu(tmp_path):
         assert m["AG"] == 1.0 and all(0 < m[k] < 1e4 for k in m)
 
 
+def test_cli_streamed_run_writes_the_same_bytes(tmp_path):
+    """The command line with --multiprocessing streams a big batch block by block (pipeline._run_streamed: stage 1, the
+    per-site loop and PI of block k on the GPU while the pool writes block k - 1's `.rates` files and a second thread fills
+    sqlite).  Forced here on 40 small loci in blocks of 16 (TPHIP_STREAM_BLOCK), in fresh processes (the pool forks before the
+    GPU is touched): every `.rates` file and every sqlite row must equal those of the unstreamed run (TPHIP_NO_STREAM)."""
+    _engine()
+    import shutil
+    import sqlite3
+    import subprocess
+    from tapir_amd import synth
+    d = synth.simulate(40, 90, 6, 21)
+    aln = tmp_path / "aln"
+    aln.mkdir()
+    tree = synth.write_nexus_dir(str(aln), d["states"].numpy(), d["locus_offsets"], d["names"], d["root"])
+    shutil.move(tree, tmp_path / "tree.newick")
+    outs = []
+    for name, env in (("streamed", {"TPHIP_STREAM_BLOCK": "16"}), ("plain", {"TPHIP_STREAM_BLOCK": "16", "TPHIP_NO_STREAM": "1"})):
+        out = tmp_path / name
+        out.mkdir()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "tapir_compute.py"), str(aln), str(tmp_path / "tree.newick"),
+                            "--output", str(out), "--times", "10,30", "--intervals", "5-15,20-40", "--multiprocessing"],
+                           capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        outs.append(out)
+    a, b = outs
+    files = sorted(f for f in os.listdir(a) if f.endswith(".rates"))
+    assert len(files) == 40 and files == sorted(f for f in os.listdir(b) if f.endswith(".rates"))
+    for f in files:
+        assert open(a / f, "rb").read() == open(b / f, "rb").read(), f
+    rows = []
+    for o in outs:
+        con = sqlite3.connect(str(o / "phylogenetic-informativeness.sqlite"))
+        rows.append({t: con.execute("SELECT * FROM %s" % t).fetchall() for t in ("loci", "net", "discrete", "interval")})
+        rows[-1]["schema"] = con.execute("SELECT sql FROM sqlite_master ORDER BY name").fetchall()
+        con.close()
+    assert rows[0] == rows[1] and len(rows[0]["loci"]) == 40 and len(rows[0]["interval"]) == 80
+
+
 def test_stage1_analytic_and_finite_difference_gradients_agree():
     """Second opinions on the engine's stage 1 (tphip_stage1_fit): the host optimiser of tapir_amd/stage1.py driven by the
     reverse-mode gradient kernel and the same optimiser driven by central differences of the value kernel reach the same
