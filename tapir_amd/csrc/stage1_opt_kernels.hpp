@@ -743,7 +743,13 @@ __global__ __launch_bounds__(256) void sub_direction_kernel(SubState S) {
     const int id = S.id[p], k = S.kk[id % kSubModels];
     double g[4], d[4], x[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) { g[a] = a < k ? S.g[(size_t)a * S.Q + p] : 0.0; x[a] = S.x[(size_t)a * S.Q + p]; }
+    for (int a = 0; a < 4; ++a) {
+        g[a] = a < k ? S.g[(size_t)a * S.Q + p] : 0.0;
+        x[a] = S.x[(size_t)a * S.Q + p];
+        // a rate AT a bound whose gradient points out of the box is fixed for this iteration (projected gradient): without
+        // this a fit whose optimum is at the bound never meets the stopping test and runs to the iteration limit
+        if ((x[a] <= kLogRateMin && g[a] > 0.0) || (x[a] >= kLogRateMax && g[a] < 0.0)) g[a] = 0.0;
+    }
     double gd = 0, gg = 0, gmax = 0;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -759,20 +765,17 @@ __global__ __launch_bounds__(256) void sub_direction_kernel(SubState S) {
         gd = -gg;
     }
     const double f = S.f[p], scale_f = 1.0 + fabs(f), last_df = S.last_df[p];
-    // Stop when the quasi-Newton model predicts that a further step gains nothing.  Unlike the general model's rule there is
-    // no condition on what the LAST step gained: the metric here starts as the Hessian of the screen's quadratic model, so
-    // its prediction is trustworthy as soon as it exists -- a fit that one Newton step has brought to its optimum is not
-    // made to take a second one to prove it (last_df = infinity, after a reset of the metric, still forces a step).
-    // (a tenth of the general model's tolerance: the screen floors the curvature of nearly flat directions at 1e-3, where the
-    // model then under-predicts what a step gains -- seen: 5e-5 gained against 2e-6 predicted)
-    const bool stop = (last_df < INFINITY && -gd <= 0.1 * kPtol * scale_f && gmax <= kGtol * scale_f) || gmax <= 1e-9;
-    if (stop) {
-        // boundary trap of the log scale: a class rate at its lower bound although the likelihood rises with the rate itself
+    // Boundary trap of the log scale, tested on EVERY iteration: a class rate near its lower bound (typically inherited from a
+    // general model that put that rate at zero) although the likelihood rises with the rate itself.  In log r both the gradient
+    // r f' and the curvature vanish there, a quasi-Newton search creeps (seen on a 3-taxon locus: 100 iterations to move a
+    // rate from 9e-4 to 2e-3 when its optimum was 0.35, 0.03-0.1 lnL short on 21 models); the rate is put at kEscapeRate and
+    // the search restarts from there with the start metric -- at most twice per fit (a rate that comes back really is zero).
+    {
         bool moved = false;
         const bool few = S.kicks[p] < 2;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-            if (a < k && x[a] < kLogRateMin + 1.0 && (g[a] / exp(x[a])) * kEscapeRate < -1e-7 * scale_f && few) {
+            if (a < k && x[a] < -3.7 /* r < kEscapeRate / 2 */ && (g[a] / exp(x[a])) * kEscapeRate < -1e-7 * scale_f && few) {
                 S.x[(size_t)a * S.Q + p] = log(kEscapeRate);
                 moved = true;
             }
@@ -783,10 +786,19 @@ __global__ __launch_bounds__(256) void sub_direction_kernel(SubState S) {
             S.last_df[p] = INFINITY;
             S.phase[p] = PH_RESTART;
             atomicAdd(&S.counters[C_NGRAD], 1);
-        } else {
-            S.phase[p] = PH_CONV;
-            atomicSub(&S.counters[C_NLIVE], 1);
+            return;
         }
+    }
+    // Stop when the quasi-Newton model predicts that a further step gains nothing.  Unlike the general model's rule there is
+    // no condition on what the LAST step gained: the metric here starts as the Hessian of the screen's quadratic model, so
+    // its prediction is trustworthy as soon as it exists -- a fit that one Newton step has brought to its optimum is not
+    // made to take a second one to prove it (last_df = infinity, after a reset of the metric, still forces a step).
+    // (a tenth of the general model's tolerance: the screen floors the curvature of nearly flat directions at 1e-3, where the
+    // model then under-predicts what a step gains -- seen: 5e-5 gained against 2e-6 predicted)
+    const bool stop = (last_df < INFINITY && -gd <= 0.1 * kPtol * scale_f && gmax <= kGtol * scale_f) || gmax <= 1e-9;
+    if (stop) {
+        S.phase[p] = PH_CONV;
+        atomicSub(&S.counters[C_NLIVE], 1);
         return;
     }
     double dmax = 0;
