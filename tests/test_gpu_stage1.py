@@ -358,6 +358,21 @@ def test_stage1_engine_call_on_degenerate_and_large_inputs():
     alone.close()
     assert np.max(np.abs(ref["pi"][0] - out["pi"][3])) < 1e-15
     assert np.max(np.abs(ref["exch"][0] - out["exch"][3]) / out["exch"][3]) < 1e-6
+    # conserved loci (a fifth of the columns vary, most branches end at their lower bound): the search must END there, not run
+    # to its iteration limit (it did, 300 iterations of 23 likelihood calls, before bound coordinates were projected out)
+    d = synth.simulate(4, 150, 32, 41, rate_mean=0.0002)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, d["locus_offsets"]))
+    plan = engine.Plan(32, pin["parent"], pin["blen"], pin["leaf"], d["locus_offsets"], pi, np.ones((4, 6)), pin["T"], [1], [[0, 1]],
+                       correction=pin["correction"])
+    a = plan.stage1_fit(st)
+    host = stage1.Stage1(plan, st, pi, pin["parent"], np.asarray(pin["blen"]))
+    b = host.run()
+    host.close()
+    plan.close()
+    assert a["grm_iters"].max() < 150 and a["stats"]["grm_evals"] < 2000, (a["grm_iters"], a["stats"])
+    assert np.all(a["lnl"][:, 0] >= b["lnl"][:, 0] - 1e-5) and np.max(np.abs(a["exch"] - b["exch"]) / b["exch"]) < 1e-3
     # 256 taxa
     L, n, nt = 3, 600, 256
     d = synth.simulate(L, n, nt, 77)
