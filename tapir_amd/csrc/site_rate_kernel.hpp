@@ -98,6 +98,18 @@ __device__ __forceinline__ ModelRegs load_model(const LocusModel* __restrict__ M
     return R;
 }
 
+// Mixed-loci mode: every lane carries the model of ITS column's locus, read straight from the (L2-resident) model rows.
+// Called under divergence: only the lanes whose locus changes load.
+__device__ __forceinline__ void load_model_lane(const LocusModel* __restrict__ M, ModelRegs& R) {
+    const double* __restrict__ m = reinterpret_cast<const double*>(M);   // lam[3] U[12] Ui[12] pi[4] kappa
+#pragma unroll
+    for (int i = 0; i < 3; ++i) R.lam[i] = m[i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { R.U[i] = m[3 + i]; R.Ui[i] = m[15 + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R.pi[i] = m[27 + i];
+}
+
 // message of a tip through its branch: P(t s) * tip, with derivatives wrt u = log s.
 // w[k] = (U^-1 tip)_k from the LDS mask table; x_k = lam_k t s; e_k = exp(x_k).
 __device__ __forceinline__ void tip_message(const ModelRegs& R, const double* __restrict__ etab, const double* w, double ts, Partial& m) {
@@ -567,13 +579,29 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const int32_t* __rest
 #ifndef TPHIP_SITE_MIN_WAVES
 #define TPHIP_SITE_MIN_WAVES 1
 #endif
-template <int NW, bool SPILL = false>
+//
+// MIXED (small batches of short loci, e.g. 1000 loci x 500 columns): the persistent scheme with EQUAL shares, but a wave
+// carries the columns of up to kMixedLoci loci at once -- every lane holds the model of its own column's locus (the model
+// registers are lane-replicated VGPRs anyway, so this costs no register) and reads the tip table of that locus (one 512-byte
+// table per locus of the group in LDS).  A wave per locus-aligned slice, the other small-batch mode, leaves the chip to the
+// slowest locus (27 rounds of evaluations against 18 on average on C2) with one wave per SIMD and a drain per locus; here
+// shares are equal column counts whatever the loci, lanes are refilled across locus boundaries and a wave drains once.
+// Results are bit-identical: a column's arithmetic does not depend on the lane or wave that carries it.
+template <int NW, bool SPILL = false, bool MIXED = false>
 __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_kernel(SiteParams P) {
     extern __shared__ double lds[];
-    double* wtab = lds;          // [16 masks][4]
-    double* mtab = lds + 64;     // [32] the locus' model
-    double* etab = lds + 96;     // [64] 2^(j/64)
-    double* stack = lds + kSiteLdsHeader;  // [stack_depth][12][64]
+    double* wtab = lds;          // [16 masks][4]          MIXED: [kMixedLoci][16][4]
+    double* mtab = lds + 64;     // [32] the locus' model  MIXED: unused, the segment table sits behind etab
+    double* etab = lds + (MIXED ? kMixedLoci * 64 : 96);     // [64] 2^(j/64)
+    double* stack = lds + (MIXED ? kMixedLdsHeader : kSiteLdsHeader);  // [stack_depth][12][64]
+    // MIXED: the loci of the current group: where a group-relative work index finds its column (work[seg_off + idx]), the
+    // index at which the locus' part ends, the locus
+    int64_t* seg_off = reinterpret_cast<int64_t*>(lds + kMixedLoci * 64 + 64);
+    int* seg_end = reinterpret_cast<int*>(seg_off + kMixedLoci);
+    int* seg_locus = seg_end + kMixedLoci;
+    int* seg_nh = seg_locus + kMixedLoci;     // slow columns at the head of the locus' part of the reordered list
+    int* seg_hcum = seg_nh + kMixedLoci;      // ... summed over the parts up to and including this one
+    int* seg_ecum = seg_hcum + kMixedLoci;    // the same for the other columns
     const int lane = threadIdx.x;
     etab[lane] = kExp2Table[lane];
     int64_t g0, g1, lo_l;
@@ -652,26 +680,131 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         }
     }
     unsigned evals = 0;
+#ifdef TPHIP_SITE_TRACE_ROUNDS
+    unsigned rounds = 0;
+    const unsigned long long tick0 = wall_clock64();
+#endif
     int64_t gpos = g0;
-    for (int64_t locus = lo_l; gpos < g1; ++locus) {
-        const int64_t pbeg = P.work_prefix[locus], pend = P.work_prefix[locus + 1];
-        const int64_t seg_end = pend < g1 ? pend : g1;
-        if (seg_end <= gpos) continue;  // locus without optimiser work
-        const int begin = (int)(gpos - pbeg), end = (int)(seg_end - pbeg);
-        gpos = seg_end;
-        __syncthreads();  // the previous segment's readers of wtab / mtab are done
-        const LocusModel* __restrict__ M = P.models + locus;
-        build_tip_table(M, wtab, lane);
-        const ModelRegs R = load_model(M, mtab, lane);
-        const double kappa = mtab[31];
-        const int32_t* __restrict__ work = ((!P.persistent && P.work_cols2) ? (const int32_t*)P.work_cols2 : P.work_cols) + P.locus_offsets[locus];
+    int64_t locus = lo_l;
+    while (gpos < g1) {
+        ModelRegs R;
+        const double* wt = wtab;     // the lane's tip table
+        double kappa = 0.0;
+        int begin, end;
+        int myk = 0, K = 1;          // MIXED: the lane's locus within the group; loci in the group
+        const int32_t* __restrict__ work;
+        if constexpr (!MIXED) {
+            const int64_t pbeg = P.work_prefix[locus], pend = P.work_prefix[locus + 1];
+            const int64_t seg_end_g = pend < g1 ? pend : g1;
+            if (seg_end_g <= gpos) { ++locus; continue; }  // locus without optimiser work
+            begin = (int)(gpos - pbeg);
+            end = (int)(seg_end_g - pbeg);
+            gpos = seg_end_g;
+            __syncthreads();  // the previous segment's readers of wtab / mtab are done
+            const LocusModel* __restrict__ M = P.models + locus;
+            build_tip_table(M, wtab, lane);
+            R = load_model(M, mtab, lane);
+            kappa = mtab[31];
+            work = ((!P.persistent && P.work_cols2) ? (const int32_t*)P.work_cols2 : P.work_cols) + P.locus_offsets[locus];
+            ++locus;
+        } else {
+            __syncthreads();  // the previous group's readers of the tables are done
+            const int64_t gb = gpos;
+            K = 0;
+            while (K < kMixedLoci && gpos < g1) {
+                const int64_t pbeg = P.work_prefix[locus], pend = P.work_prefix[locus + 1];
+                const int64_t se = pend < g1 ? pend : g1;
+                if (se > gpos) {
+                    if (lane == 0) {
+                        seg_off[K] = P.locus_offsets[locus] - pbeg + gb;
+                        seg_end[K] = (int)(se - gb);
+                        seg_locus[K] = (int)locus;
+                    }
+                    build_tip_table(P.models + locus, wtab + 64 * K, lane);
+                    ++K;
+                    gpos = se;
+                }
+                if (pend <= gpos) ++locus;
+            }
+            begin = 0;
+            end = (int)(gpos - gb);
+            __threadfence_block();
+            __syncthreads();
+            if (P.work_cols2) {   // slow columns first inside every locus' part (see the small-batch mode above)
+                for (int k = 0; k < K; ++k) {
+                    const int32_t* __restrict__ src = P.work_cols + seg_off[k];
+                    int32_t* __restrict__ dst = P.work_cols2 + seg_off[k];
+                    const int b = k ? seg_end[k - 1] : 0, e = seg_end[k];
+                    int nh = 0;
+                    for (int i = b; i < e; i += kSiteBlock) {
+                        const bool in = i + lane < e;
+                        const int32_t c = src[in ? i + lane : b];
+                        nh += __popcll(__ballot(in && P.lnl[c] != 0.0));
+                    }
+                    if (lane == 0) seg_nh[k] = nh;
+                    int ph = b, pe = b + nh;
+                    for (int i = b; i < e; i += kSiteBlock) {
+                        const bool in = i + lane < e;
+                        const int32_t c = src[in ? i + lane : b];
+                        const bool hard = in && P.lnl[c] != 0.0;
+                        const unsigned long long mh = __ballot(hard), me = __ballot(in && !hard);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        if (hard) dst[ph + __popcll(mh & below)] = c;
+                        else if (in) dst[pe + __popcll(me & below)] = c;
+                        ph += __popcll(mh);
+                        pe += __popcll(me);
+                    }
+                }
+            } else if (lane < K) {
+                seg_nh[lane] = 0;
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (lane == 0) {   // the slow columns of ALL parts are handed out first, then the rest, part by part
+                int hc = 0, ec = 0;
+                for (int k = 0; k < K; ++k) {
+                    const int b = k ? seg_end[k - 1] : 0;
+                    hc += seg_nh[k];
+                    ec += seg_end[k] - b - seg_nh[k];
+                    seg_hcum[k] = hc;
+                    seg_ecum[k] = ec;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            work = P.work_cols2 ? (const int32_t*)P.work_cols2 : P.work_cols;
+            R.c4 = 4.1666666666666664e-02;
+            asm volatile("" : "+v"(R.c4));
+        }
+        // MIXED: the column at group-relative work index idx, with its locus' position in the group in the top four bits
+        auto fetch = [&](int idx) -> int32_t {
+            if constexpr (!MIXED) return work[idx];
+            const int H = seg_hcum[K - 1];
+            const bool slow = idx < H;
+            const int e = slow ? idx : idx - H;
+            const int* cum = slow ? seg_hcum : seg_ecum;
+            int k = 0;
+            for (int j = 0; j + 1 < K; ++j) k += (e >= cum[j]) ? 1 : 0;
+            // position in the (reordered) list of part k: its slow columns come first
+            const int pos = (k ? seg_end[k - 1] : 0) + (slow ? 0 : seg_nh[k]) + e - (k ? cum[k - 1] : 0);
+            return work[seg_off[k] + pos] | (k << 28);
+        };
 
         int next = begin + kSiteBlock;  // wave-uniform: first work index not yet handed to a lane
         bool done = (begin + lane >= end);
-        int64_t col = work[done ? begin : begin + lane];
+        int64_t col;
+        {
+            const int32_t c0 = fetch(done ? begin : begin + lane);
+            col = MIXED ? (c0 & 0x0fffffff) : c0;
+            if constexpr (MIXED) {
+                myk = c0 >> 28;
+                load_model_lane(P.models + seg_locus[myk], R);
+                wt = wtab + 64 * myk;
+            }
+        }
         // the next 64 candidates of the work list, one per lane, requested an evaluation before a refill needs them: the
         // refill then costs one memory round trip (the column's packed tips and start value), not two
-        int32_t cand = work[next + lane < end ? next + lane : end - 1];
+        int32_t cand = fetch(next + lane < end ? next + lane : end - 1);
         uint32_t pk[NW > 0 ? NW : 1] = {0};
 #pragma unroll
         for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
@@ -686,7 +819,10 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
         int it = 0;
         while (true) {
             double f, g, h;
-            evaluate_site<NW, SPILL>(P, R, wtab, etab, stack, col, pk, exp(u), f, g, h);
+            evaluate_site<NW, SPILL>(P, R, wt, etab, stack, col, pk, exp(u), f, g, h);
+#ifdef TPHIP_SITE_TRACE_ROUNDS
+            ++rounds;
+#endif
             if (!done) {
                 const double f_eval = f;
                 ++evals;
@@ -804,6 +940,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     if (flg < 0 && it >= kMaxIt) flg = TPHIP_FLAG_MAXIT;
                 }
                 if (flg >= 0) {  // this column is finished: write it out, the lane becomes free
+                    if constexpr (MIXED) kappa = reinterpret_cast<const double*>(P.models + seg_locus[myk])[31];
                     const double r = exp(u) * kappa;
                     P.rate[col] = r;
                     P.subst[col] = r * P.chrono_length;
@@ -820,7 +957,15 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                 const int idx = next + rank;
                 const int32_t picked = __shfl(cand, rank);   // = work[next + rank]
                 if (done && idx < end) {
-                    col = picked;
+                    col = MIXED ? (picked & 0x0fffffff) : picked;
+                    if constexpr (MIXED) {
+                        const int nk = picked >> 28;
+                        if (nk != myk) {   // the lane moves on to another locus: its model and tip table
+                            myk = nk;
+                            load_model_lane(P.models + seg_locus[nk], R);
+                            wt = wtab + 64 * nk;
+                        }
+                    }
 #pragma unroll
                     for (int w = 0; w < NW; ++w) pk[w] = (w < P.nwords) ? P.packed[(int64_t)w * P.ncols_total + col] : 0u;
                     if constexpr (NW == kStreamWords) pk[0] = P.packed[col];
@@ -829,7 +974,7 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     done = false;
                 }
                 next += __popcll(free_mask);
-                if (next < end) cand = work[next + lane < end ? next + lane : end - 1];
+                if (next < end) cand = fetch(next + lane < end ? next + lane : end - 1);
             } else if (free_mask == ~0ull) {
                 break;  // segment exhausted and every lane finished
             }
@@ -840,6 +985,16 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (lane == 0 && P.eval_counter) atomicAdd(P.eval_counter, (unsigned long long)tot);
+#ifdef TPHIP_SITE_TRACE_ROUNDS   // diagnostic build: rounds and wall-clock ticks (100 MHz) per wave, sum and maximum
+    if (lane == 0 && P.eval_counter) {
+        const unsigned long long ticks = wall_clock64() - tick0;
+        atomicAdd(P.eval_counter + 1, (unsigned long long)rounds);
+        atomicMax(P.eval_counter + 2, (unsigned long long)rounds);
+        atomicAdd(P.eval_counter + 3, ticks);
+        atomicMax(P.eval_counter + 4, ticks);
+        atomicAdd(P.eval_counter + 5, 1ull);
+    }
+#endif
 }
 
 // Diagnostic: evaluate f = log L, g = df/du, h = d2f/du2 at a caller-chosen u for EVERY column (no

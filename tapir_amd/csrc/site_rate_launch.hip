@@ -19,6 +19,8 @@ hipError_t launch_site_rate_kernel(int variant, dim3 grid, size_t lds_bytes, hip
     if (variant == 0) site_rate_kernel<0><<<grid, block, lds_bytes, st>>>(S);
     else if (variant == 2) site_rate_kernel<2><<<grid, block, lds_bytes, st>>>(S);
     else if (variant == 8) site_rate_kernel<8><<<grid, block, lds_bytes, st>>>(S);
+    else if (variant == kMixedVariant + 2) site_rate_kernel<2, false, true><<<grid, block, lds_bytes, st>>>(S);
+    else if (variant == kMixedVariant + 8) site_rate_kernel<8, false, true><<<grid, block, lds_bytes, st>>>(S);
     else if (variant == kStreamWords) site_rate_kernel<kStreamWords><<<grid, block, lds_bytes, st>>>(S);
     else if (variant == kStreamWordsSpill) site_rate_kernel<kStreamWords, true><<<grid, block, lds_bytes, st>>>(S);
     else return hipErrorInvalidValue;
@@ -29,6 +31,8 @@ hipError_t site_rate_kernel_occupancy(int variant, size_t lds_bytes, int* blocks
     if (variant == 0) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<0>, kSiteBlock, lds_bytes);
     if (variant == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<2>, kSiteBlock, lds_bytes);
     if (variant == 8) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<8>, kSiteBlock, lds_bytes);
+    if (variant == kMixedVariant + 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<2, false, true>, kSiteBlock, lds_bytes);
+    if (variant == kMixedVariant + 8) return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<8, false, true>, kSiteBlock, lds_bytes);
     if (variant == kStreamWords)
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, site_rate_kernel<kStreamWords>, kSiteBlock, lds_bytes);
     if (variant == kStreamWordsSpill)

@@ -31,6 +31,9 @@ constexpr double kUCheck = 2.995732273553991;   // log(20)
 constexpr double kSatTol = 1e-10;
 constexpr double kPlateauStride = 0.5;
 constexpr int kSiteBlock = 64;      // one wavefront per workgroup
+constexpr int kMixedLoci = 8;        // loci whose columns a wave of the mixed-loci mode carries at a time (site_rate_kernel.hpp)
+constexpr int kMixedLdsHeader = kMixedLoci * 64 + 64 + 32;   // doubles: tip tables, 2^(j/64), segment table
+constexpr int kMixedColBits = 28;    // a work entry of that mode = column | locus-in-group << 28: batches below 2^28 columns
 constexpr int kSiteLdsHeader = 160;  // doubles of LDS before the stack: tip table [16][4] + model [32] + 2^(j/64) [64]
 #ifndef TPHIP_EXP_TABLE
 #define TPHIP_EXP_TABLE 1
@@ -59,6 +62,7 @@ struct SiteParams {
     const int64_t* slice_prefix;   // [nloci+1] exclusive scan of the per-locus slice counts (non-persistent mode)
     int64_t nloci;
     int32_t persistent;            // 1: grid = resident waves (x grid multiplier), shares of the global work list; 0: grid = slices
+                                   // (the mixed-loci variants are launched with 1 and equal shares)
     int32_t first_round;           // persistent: the first `first_round` workgroups (one per resident wave) share
     double first_fraction;         //   this fraction of the work equally, the others the rest (see site_rate_kernel)
     int32_t ncat;                  // > 1: discrete rate mixture on top of the site rate (tphip_plan_desc.ncat)
@@ -81,6 +85,7 @@ __host__ __device__ __forceinline__ int site_slices(int count, int chunk_cols) {
 
 constexpr int kStreamWords = -1;   // NW value of the streamed-words path
 constexpr int kStreamWordsSpill = -2;   // launcher variant: streamed words + SPILL
+constexpr int kMixedVariant = 100;   // launcher variants 102 / 108: packed words in registers, mixed-loci mode
 
 // Diagnostic launch: evaluate f = log L, g = df/du, h = d2f/du2 at a caller-chosen u for EVERY column.
 struct EvalParams {

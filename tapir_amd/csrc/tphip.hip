@@ -339,8 +339,8 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
     if (e == hipSuccess) e = p->d_times.upload(times);
     if (e == hipSuccess) e = p->d_intervals.upload(iv);
     if (e == hipSuccess) e = p->d_models.alloc((size_t)d->nloci);
-    if (e == hipSuccess) e = p->d_evals.alloc(1);
-    if (e == hipSuccess) e = hipMemset(p->d_evals.p, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = p->d_evals.alloc(8);   // [0] evaluations; [1..5] diagnostics of a TPHIP_SITE_TRACE_ROUNDS build
+    if (e == hipSuccess) e = hipMemset(p->d_evals.p, 0, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = d_pi.upload(hpi);
     if (e == hipSuccess) e = d_exch.upload(hex);
     if (e == hipSuccess) {
@@ -452,6 +452,29 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
         if (!p->site_persistent && p->site_lds_depth < p->prog.stack_depth) {   // the scratch rows are per persistent wave
             p->site_lds_depth = p->prog.stack_depth;
             p->site_waves = per_cu * prop.multiProcessorCount;
+        }
+        // Small batches of trees up to 64 taxa: equal shares of the work list, a wave carrying columns of several loci at
+        // once (site_rate_kernel<NW, false, true>); the slice mode remains for the streamed-words and byte paths.
+        p->site_mixed = (!p->site_persistent && p->nwords <= 8 && !p->force_byte_path && ncols < ((int64_t)1 << kMixedColBits)) ? 1 : 0;
+        if (const char* em = getenv("TPHIP_SITE_MIXED")) p->site_mixed = (em[0] == '1') && p->nwords <= 8 && !p->force_byte_path && ncols < ((int64_t)1 << kMixedColBits);
+        if (p->site_mixed) {
+            int per3 = 0;
+            const size_t lds3 = (kMixedLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+            if (lds3 > 160 * 1024 || site_rate_kernel_occupancy(kMixedVariant + (p->nwords <= 2 ? 2 : 8), lds3, &per3) != hipSuccess || per3 < 1) p->site_mixed = 0;
+            else {
+                p->site_persistent = 0;
+                // One wave per SIMD or two?  A second wave on a SIMD adds half again to its throughput (C2: 15.2 us per round of
+                // evaluations alone, 19.8 us each for two) but lengthens every round of the wave that carries the slowest column
+                // (22 evaluations on C2 when the average column takes 3.7), and the launch ends with that wave.  Measured on C2
+                // (~17 rounds per SIMD): 1024 waves 0.348 ms, 2048 waves 0.391, 1152 waves 0.422 (SIMDs shared unevenly); the
+                // estimate puts the crossover near 28 rounds per SIMD.  Rounds are estimated from the column count: ~0.6 of
+                // the columns need the optimiser, 3.7 evaluations each from HyPhy's start value, 2.4 from the parsimony start.
+                const int64_t simds = 4 * (int64_t)prop.multiProcessorCount;
+                const double est_rounds = (double)ncols * (p->start_rule == TPHIP_START_REFERENCE ? 2.2 : 1.4) / (double)(kSiteBlock * simds);
+                const int64_t want = (est_rounds < 28.0) ? std::min<int64_t>(simds, (int64_t)per3 * prop.multiProcessorCount)
+                                                         : (int64_t)std::min(per3, 8) * prop.multiProcessorCount;
+                p->site_waves = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, (ncols + kSiteBlock - 1) / kSiteBlock));
+            }
         }
         if (const char* e2 = getenv("TPHIP_SITE_WAVES")) { long v = atol(e2); if (v >= 1) p->site_waves = (int32_t)v; }  // tuning knob
         // Share sizes of the persistent grid.  Equal shares (one per resident wave) are equal column counts, not equal
@@ -593,6 +616,12 @@ int tphip_last_eval_count(tphip_plan* p, int64_t* evals) {
         }
     } else {
         HIP_TRY(hipMemcpy(&v, p->d_evals.p, sizeof v, hipMemcpyDeviceToHost));
+        if (getenv("TPHIP_SITE_TRACE_ROUNDS")) {   // meaningful in a -DTPHIP_SITE_TRACE_ROUNDS build only
+            unsigned long long c[8];
+            HIP_TRY(hipMemcpy(c, p->d_evals.p, sizeof c, hipMemcpyDeviceToHost));
+            if (c[5]) fprintf(stderr, "site_rate_kernel: %llu waves with work, evaluations %llu, rounds mean %.1f max %llu (lane use %.1f %%), wave time mean %.1f us max %.1f us\n",
+                              c[5], c[0], (double)c[1] / c[5], c[2], 100.0 * c[0] / (64.0 * c[1]), 0.01 * c[3] / c[5], 0.01 * c[4]);
+        }
     }
     *evals = (int64_t)v;
     return TPHIP_OK;
@@ -640,7 +669,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
         HIP_TRY(launch_scan_counts_kernel(st, work_count, p->nloci, p->site_chunk_cols, (int64_t*)((char*)ws + p->ws_work_prefix),
                                           (int64_t*)((char*)ws + p->ws_slice_prefix)));
     }
-    HIP_TRY(hipMemsetAsync(p->d_evals.p, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(p->d_evals.p, 0, 8 * sizeof(unsigned long long), st));
     SiteParams S;
     S.states = d_states; S.ncols_total = p->ncols; S.models = p->d_models.p; S.ops = p->d_ops.p;
     S.nops = (int32_t)p->prog.ops.size(); S.stack_depth = p->prog.stack_depth; S.chrono_length = p->prog.chrono_length;
@@ -656,14 +685,15 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     const size_t lds = (kSiteLdsHeader + (size_t)p->site_lds_depth * 12 * kSiteBlock) * sizeof(double);
     S.lds_depth = p->site_lds_depth;
     S.spill = spill ? (double*)((char*)ws + p->ws_spill) : nullptr;
-    S.persistent = p->site_persistent;
+    S.persistent = (p->site_persistent || p->site_mixed) ? 1 : 0;
     S.first_round = p->site_waves;
     S.first_fraction = (p->site_first_fraction > 0.0) ? p->site_first_fraction : 1.0 / (double)p->site_grid_mult;
     S.ncat = p->ncat; S.cat = p->d_cat.p;
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 0], st));
     if (p->n_site_chunks > 0) {
-        const dim3 grid((unsigned)(p->site_persistent ? p->site_waves * p->site_grid_mult : p->n_site_chunks));
+        const bool mixed = p->site_mixed && !p->force_byte_path;
+        const dim3 grid((unsigned)(mixed ? p->site_waves : p->site_persistent ? p->site_waves * p->site_grid_mult : p->n_site_chunks));
         // packed tip states: in registers up to 64 tips, streamed one word ahead beyond (site_rate_kernel.hpp)
         const bool byte_path = p->force_byte_path;   // test/tuning knob, resolved at plan creation
         if (!byte_path) {  // the packed path reads the stream with fused cherries (tree_program.hpp)
@@ -674,6 +704,11 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
         const size_t lds_full = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
         const int variant = byte_path ? 0 : p->nwords <= 2 ? 2 : p->nwords <= 8 ? 8 : (spill ? kStreamWordsSpill : kStreamWords);
         if (byte_path) { S.lds_depth = p->prog.stack_depth; S.spill = nullptr; }
+        if (mixed) {   // equal shares: first_round = grid
+            const size_t lds_mixed = (kMixedLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+            S.first_fraction = 1.0;
+            HIP_TRY(launch_site_rate_kernel(kMixedVariant + variant, grid, lds_mixed, st, S));
+        } else
         HIP_TRY(launch_site_rate_kernel(variant, grid, (byte_path || !spill) ? lds_full : lds, st, S));
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(p->ev[4 * slot + 1], st));

@@ -546,14 +546,15 @@ def test_all_gap_and_ragged_loci(oracle):
     plan.close()
 
 
-@pytest.mark.parametrize("persistent,byte_path", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
-def test_site_rate_kernel_variants(oracle, monkeypatch, persistent, byte_path):
-    """Every scheduling mode (persistent equal shares / locus-aligned slices) and both tip-state paths
-    (register-resident packed words / one-op-ahead byte loads) against the oracle on the same bytes."""
+@pytest.mark.parametrize("persistent,byte_path,mixed", [("0", "0", "0"), ("0", "0", "1"), ("1", "0", "0"), ("0", "1", "0"), ("1", "1", "0")])
+def test_site_rate_kernel_variants(oracle, monkeypatch, persistent, byte_path, mixed):
+    """Every scheduling mode (persistent equal shares / locus-aligned slices / waves carrying several loci) and both
+    tip-state paths (register-resident packed words / one-op-ahead byte loads) against the oracle on the same bytes."""
     engine = _engine()
     from tapir_amd import synth
     monkeypatch.setenv("TPHIP_SITE_PERSISTENT", persistent)
     monkeypatch.setenv("TPHIP_FORCE_BYTE_PATH", byte_path)
+    monkeypatch.setenv("TPHIP_SITE_MIXED", mixed)
     for ntaxa, nloci, ncols, seed in [(20, 9, 777, 31), (130, 3, 300, 32)]:
         d = synth.simulate(nloci, ncols, ntaxa, seed)
         pin = synth.plan_inputs(d["root"], d["names"])
@@ -574,6 +575,43 @@ def test_site_rate_kernel_variants(oracle, monkeypatch, persistent, byte_path):
             _assert_rates_match(oracle, got, ref, sl, st[:, sl], pin, d["pi"][l], d["exch"][l], kappa[l])
             assert np.abs(got["lnl"][sl] - ref["lnl"]).max() < 1e-10 * max(1.0, np.abs(ref["lnl"]).max())
         plan.close()
+
+
+@pytest.mark.parametrize("ntaxa", [12, 40])
+def test_mixed_loci_mode_is_bit_identical(monkeypatch, ntaxa):
+    """Small batches of short loci run with waves that carry columns of several loci at once, each lane holding its own
+    locus' model.  A column's arithmetic does not depend on the lane or wave that carries it: every output
+    equals the slice mode's and the persistent mode's bit for bit -- ragged loci from 0 to 200 columns, shares that span
+    more loci than one group holds (few waves), one- and four-word trees; default mode = mixed on this shape."""
+    engine = _engine()
+    from tapir_amd import synth
+    rng = np.random.default_rng(77 + ntaxa)
+    nloci = 300
+    d = synth.simulate(nloci, 200, ntaxa, 900 + ntaxa)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    lens = rng.integers(0, 201, size=nloci)
+    tiny = rng.random(nloci) < 0.3
+    lens[tiny] = rng.integers(0, 4, size=int(tiny.sum()))        # runs of loci with 0-3 columns
+    off = np.zeros(nloci + 1, dtype=np.int64)
+    off[1:] = np.cumsum(lens)
+    st = np.ascontiguousarray(st[:, : int(off[-1])])
+    runs = {}
+    for name, env in [("default", {}), ("mixed", dict(TPHIP_SITE_MIXED="1")), ("mixed_few_waves", dict(TPHIP_SITE_MIXED="1", TPHIP_SITE_WAVES="5")),
+                      ("slices", dict(TPHIP_SITE_MIXED="0", TPHIP_SITE_PERSISTENT="0")), ("persistent", dict(TPHIP_SITE_MIXED="0", TPHIP_SITE_PERSISTENT="1"))]:
+        for k in ("TPHIP_SITE_MIXED", "TPHIP_SITE_WAVES", "TPHIP_SITE_PERSISTENT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = engine.Plan(ntaxa, pin["parent"], pin["blen"], pin["leaf"], off, d["pi"], d["exch"], pin["T"], [10], [[5, 15]],
+                           correction=pin["correction"])
+        runs[name] = plan.run_fused(st)
+        plan.close()
+    base = runs["slices"]
+    assert (base["flag"] == 0).sum() > off[-1] // 4
+    for name, got in runs.items():
+        for key in ("rate", "subst", "lnl", "flag", "nres", "tables"):
+            assert np.array_equal(got[key], base[key]), (name, key)
 
 
 @pytest.mark.parametrize("ntaxa,ncols,kw", [(9, 30000, dict(rate_mean=0.05, gap_frac=0.3)), (64, 20000, dict(rate_mean=0.3)),
