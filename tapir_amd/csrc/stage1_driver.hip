@@ -226,6 +226,7 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
     SubState B;
     struct Extra {
         int32_t* counters; int32_t *branches, *node_coord, *partner; double *dk, *shape, *grid, *node_w; int8_t* cls; int32_t* kk;
+        int32_t *parent, *leaf; double* pchanges;
         double *grm_exch, *grm_blen, *stash, *grm_lnl; uint8_t* flags; int32_t* sub_iters; void* cub_tmp; int32_t* nsel;
         double *o_weights, *o_lnl, *o_mexch, *o_exch, *pi; unsigned long long* hist;
     } X;
@@ -238,6 +239,7 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
         X.counters = A.take<int32_t>(C_COUNT);
         X.branches = A.take<int32_t>(nb); X.node_coord = A.take<int32_t>(nn); X.partner = A.take<int32_t>(nb);
         X.node_w = A.take<double>(nn); X.dk = A.take<double>(P * 6);
+        X.parent = A.take<int32_t>(nn); X.leaf = A.take<int32_t>(nn); X.pchanges = A.take<double>(P * (nn + 1));
         X.shape = A.take<double>(nn); X.grid = A.take<double>(ngrid); X.cls = A.take<int8_t>(kSubModels * 6); X.kk = A.take<int32_t>(kSubModels);
         X.grm_exch = A.take<double>(P * 6); X.grm_blen = A.take<double>(P * nn); X.stash = A.take<double>(P * nn); X.grm_lnl = A.take<double>(P);
         X.flags = A.take<uint8_t>(LM); X.sub_iters = A.take<int32_t>(LM); X.cub_tmp = A.take<char>(cub_bytes); X.nsel = A.take<int32_t>(1);
@@ -298,6 +300,8 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
     HIP_TRY(hipMemcpyAsync(X.partner, partner.data(), sizeof(int32_t) * nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.node_w, node_w.data(), sizeof(double) * nn, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.shape, h_shape.data(), sizeof(double) * nn, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(X.parent, desc->parent, sizeof(int32_t) * nn, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(X.leaf, desc->leaf_taxon, sizeof(int32_t) * nn, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.grid, h_grid.data(), sizeof(double) * ngrid, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.cls, h_cls.data(), sizeof(int8_t) * kSubModels * 6, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(X.kk, h_kk.data(), sizeof(int32_t) * kSubModels, hipMemcpyHostToDevice, st));
@@ -346,8 +350,38 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
     hipLaunchKernelGGL(grm_grid_emit_kernel, dim3(blocks_for((int64_t)L * ngrid, 256)), dim3(256), 0, st, G.C, L, ngrid, X.grid);
     KCHECK();
     RC(dr.value(G.C, X.shape, (int64_t)L * ngrid));
+    HIP_TRY(hipMemsetAsync(X.counters + C_PARS, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(grm_grid_pick_kernel, dim3(blocks_for(L, 256)), dim3(256), 0, st, G, ngrid, X.grid, X.shape);
     KCHECK();
+    // Second start: per-branch parsimony counts shrunk towards the grid start (one more likelihood per locus); the better of
+    // the two is kept.  The input tree's shape is what the reference hands HyPhy, and on loci that follow it the grid start is
+    // hard to beat (21.2 iterations against 22.0); but where the input lengths are off -- each branch by a factor exp(N(0, 2)):
+    // 36 iterations from the grid start, and 472 of 500 loci end hundreds of log-units lower with a few branches parked at
+    // saturating lengths, where the gradient vanishes -- the counts keep every start inside the region the data support
+    // (24.7 iterations, tools/debug/s1_start_perturbed.py).  TPHIP_S1_START = grid | shrunk (default) | pars | both.
+    {
+        bool postorder = nn <= kParsMaxNodes && desc->parent[nn - 1] < 0;
+        for (int n = 0; n + 1 < nn && postorder; ++n) postorder = desc->parent[n] > n && desc->parent[n] < nn;
+        const char* env = getenv("TPHIP_S1_START");
+        if (postorder && !(env && !strcmp(env, "grid"))) {
+            HIP_TRY(hipMemsetAsync(X.pchanges, 0, sizeof(double) * (size_t)P * (nn + 1), st));
+            const int64_t maxc = p->max_locus_cols;   // (of the pattern view when one is installed)
+            const unsigned ny = (unsigned)std::min<int64_t>(64, std::max<int64_t>(1, (maxc + 1023) / 1024));
+            hipLaunchKernelGGL(branch_parsimony_kernel, dim3((unsigned)L, ny), dim3(128), sizeof(double) * (nn + 1), st, d_states, p->ncols,
+                               p->d_offsets.p, p->d_col_weight, nn, X.parent, X.leaf, X.pchanges);
+            KCHECK();
+            const double alpha_env = getenv("TPHIP_S1_PARS_ALPHA") ? atof(getenv("TPHIP_S1_PARS_ALPHA")) : 0.5;
+            for (int pass = 0; pass < 2; ++pass) {   // the counts shrunk towards the grid start; the counts alone (experiments)
+                const bool on = pass == 0 ? !(env && !strcmp(env, "pars")) : (env && (!strcmp(env, "pars") || !strcmp(env, "both")));
+                if (!on) continue;
+                hipLaunchKernelGGL(grm_pars_emit_kernel, dim3((unsigned)L), dim3(64), sizeof(double) * D, st, G, X.pchanges, pass == 0 ? alpha_env : -1.0);
+                KCHECK();
+                RC(dr.value(G.C, G.vecs, (int64_t)L));
+                hipLaunchKernelGGL(grm_pars_pick_kernel, dim3((unsigned)L), dim3(64), 0, st, G, X.counters + C_PARS, 0.0);
+                KCHECK();
+            }
+        }
+    }
     // optimiser state
     HIP_TRY(hipMemsetAsync(G.rho, 0, sizeof(double) * kHistory * P, st));
     HIP_TRY(hipMemsetAsync(G.nhist, 0, sizeof(int32_t) * P, st));
@@ -361,7 +395,7 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
         HIP_TRY(hipMemcpyAsync(G.last_df, infs.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
-    RC(dr.zero(0, C_COUNT));
+    RC(dr.zero(0, C_PARS));   // (C_PARS, the last one, was counted by the start above)
     RC(dr.set_counter(C_NLIVE, L));
     auto grm_gradient = [&](int64_t n) -> int {
         if (n <= 0) return TPHIP_OK;
@@ -381,6 +415,7 @@ extern "C" int tphip_stage1_fit_dev(tphip_plan* p, const uint8_t* d_states, cons
         hipLaunchKernelGGL(grm_direction_kernel, dim3(L), dim3(64), sizeof(double) * D, st, G);
         KCHECK();
         RC(dr.read_counters());
+        if (it == 0 && trace >= 0) fprintf(stderr, "stage 1: the parsimony start beat the grid start on %d of %d loci\n", h_counters[C_PARS], L);
         if (h_counters[C_NLIVE] <= 0) break;
         ++grm_iterations;
         int npend = h_counters[C_NPEND];

@@ -35,7 +35,7 @@ constexpr int kModels = 203, kSubModels = 202;
 constexpr int kScreenPoints = 31;
 constexpr double kScreenStep = 2e-2;
 
-enum : int32_t { C_NCAND = 0, C_NLIVE = 1, C_NPEND = 2, C_NGRAD = 3, C_NFAILED = 4, C_NPRUNED = 5, C_NKEEP = 6, C_COUNT = 8 };
+enum : int32_t { C_NCAND = 0, C_NLIVE = 1, C_NPEND = 2, C_NGRAD = 3, C_NFAILED = 4, C_NPRUNED = 5, C_NKEEP = 6, C_PARS = 7, C_COUNT = 8 };
 enum : uint8_t { PH_LIVE = 0, PH_PEND = 1, PH_ACCEPTED = 2, PH_FAILED = 3, PH_RESTART = 4, PH_CONV = 5, PH_INIT = 6 };
 
 // flat candidate arrays in the layout tphip_locus_loglik_dev / tphip_locus_gradient_dev take
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void grm_grid_pick_kernel(GrmState G, int32_t 
         const double v = G.C.out[(size_t)p * ngrid + k];
         if (v > bv) { bv = v; best = k; }
     }
+    G.fnew[p] = bv;   // for the comparison with the parsimony start (grm_pars_pick_kernel)
     double tf = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) tf += G.dk[(size_t)p * 6 + q];
@@ -450,6 +451,92 @@ __global__ __launch_bounds__(256) void grm_grid_pick_kernel(GrmState G, int32_t 
         const int n = G.branches[j], n2 = G.partner[j];
         x[5 + j] = log(grid[best] * (shape[n] + (n2 >= 0 ? shape[n2] : 0.0)) * tf);
     }
+    for (int j = 0; j < G.D; ++j) G.d[(size_t)p * G.D + j] = x[j];   // the prior of the shrunk parsimony start
+}
+
+// ---- second start of the branch lengths: per-branch parsimony counts --------------------------------------
+// changes[l][n] += weight of the columns of locus l whose most parsimonious reconstruction changes state on the branch above
+// node n; changes[l][nn] += total weight.  Fitch's two passes per column over the post-order node numbering (children before
+// parents, root last -- checked by the caller): down, the state sets (tips: their 4-bit masks, a gap = all four); up, the
+// parent's state where the child's set allows it, else the child's lowest state and one change.  thread = column, a block's
+// counts gathered in LDS, one global atomic per (block, branch).
+constexpr int kParsMaxNodes = 1024;
+__global__ __launch_bounds__(128) void branch_parsimony_kernel(const uint8_t* states, int64_t ncols_total, const int64_t* locus_offsets,
+                                                               const double* col_weight, int32_t nn, const int32_t* parent,
+                                                               const int32_t* leaf_taxon, double* changes) {
+    extern __shared__ double acc[];   // [nn + 1]
+    const int l = blockIdx.x;
+    for (int n = threadIdx.x; n <= nn; n += blockDim.x) acc[n] = 0.0;
+    __syncthreads();
+    const int64_t lo = locus_offsets[l], hi = locus_offsets[l + 1];
+    for (int64_t col = lo + (int64_t)blockIdx.y * blockDim.x + threadIdx.x; col < hi; col += (int64_t)gridDim.y * blockDim.x) {
+        uint8_t set[kParsMaxNodes];
+        for (int n = 0; n < nn; ++n) {
+            const int t = leaf_taxon[n];
+            unsigned m = 0;
+            if (t >= 0) { m = states[(int64_t)t * ncols_total + col] & 15u; m = m ? m : 15u; }
+            set[n] = (uint8_t)m;
+        }
+        for (int n = 0; n + 1 < nn; ++n) {
+            const int pa = parent[n];
+            const unsigned a = set[pa], c = set[n], both = a & c;
+            set[pa] = (uint8_t)(a == 0 ? c : (both ? both : (a | c)));
+        }
+        const double w = col_weight ? col_weight[col] : 1.0;
+        { const unsigned r = set[nn - 1]; set[nn - 1] = (uint8_t)(r & (0u - r)); }
+        for (int n = nn - 2; n >= 0; --n) {
+            const unsigned ps = set[parent[n]], c = set[n];
+            if (c & ps) set[n] = (uint8_t)ps;
+            else {
+                set[n] = (uint8_t)(c & (0u - c));
+                if (c) atomicAdd(&acc[n], w);
+            }
+        }
+        atomicAdd(&acc[nn], w);
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n <= nn; n += blockDim.x)
+        if (acc[n] != 0.0) atomicAdd(&changes[(size_t)l * (nn + 1) + n], acc[n]);
+}
+// the parsimony point of every problem: rates 1, b = -3/4 log(1 - 4/3 p) with p = changes per column on the branch (at least
+// kParsFloor changes, at most 0.6 per column) -> G.xt and value candidate p.  block = one wave = one problem
+constexpr double kParsFloor = 0.3;
+// alpha >= 0: the counts shrunk towards the grid start b0 (kept in G.d by grm_grid_pick_kernel) as a Gamma prior of alpha
+// pseudo-changes: b = (b_pars W + alpha) / (W + alpha / b0) -- branches with many changes follow the data, branches with
+// hardly any follow the input tree's shape
+__global__ __launch_bounds__(64) void grm_pars_emit_kernel(GrmState G, const double* changes, double alpha) {
+    extern __shared__ double xs[];   // [D]
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const double* ch = changes + (size_t)p * (G.nn + 1);
+    const double W = fmax(ch[G.nn], 1.0);
+    double* xt = G.xt + (size_t)p * G.D;
+    for (int j = lane; j < G.D; j += 64) {
+        double v = 0.0;
+        if (j >= 5) {
+            const int n = G.branches[j - 5], n2 = G.partner[j - 5];
+            const double c = ch[n] + (n2 >= 0 ? ch[n2] : 0.0);
+            const double pc = fmin(fmax(c, alpha >= 0.0 ? 0.0 : kParsFloor) / W, 0.6);
+            double b = -0.75 * log1p(-pc * (4.0 / 3.0));
+            if (alpha >= 0.0) {
+                const double b0 = exp(G.d[(size_t)p * G.D + j]);
+                b = (b * W + alpha) / (W + alpha / b0);
+            }
+            v = fmax(fmin(log(b), kLogBlenMax), kLogBlenMin);
+        }
+        xt[j] = v;
+        xs[j] = v;
+    }
+    __syncthreads();
+    grm_emit_point(G, p, xs, p);
+}
+// keep the better of the two starts (G.fnew holds the grid start's log-likelihood, candidate p the parsimony point's)
+__global__ __launch_bounds__(64) void grm_pars_pick_kernel(GrmState G, int32_t* taken, double margin) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const double v = G.C.out[p];
+    if (!(isfinite(v) && v > G.fnew[p] + margin)) return;
+    for (int j = lane; j < G.D; j += 64) G.x[(size_t)p * G.D + j] = G.xt[(size_t)p * G.D + j];
+    if (lane == 0) G.fnew[p] = v;
+    if (lane == 0 && taken) atomicAdd(taken, 1);
 }
 
 // fitted general model -> exchangeabilities [P][6], branch lengths t = b / totalFactor [P][nn], stash b [P][nn], lnL [P]

@@ -391,6 +391,43 @@ def test_stage1_engine_call_on_degenerate_and_large_inputs():
     assert np.max(np.abs(a["weights"] - b["weights"])) < 2e-3   # (two optimisers on 510 branch lengths: the stash differs within tolerance)
 
 
+def test_stage1_start_from_branch_parsimony_counts(monkeypatch):
+    """The general model starts from the better of two points: the input tree's shape at the best of 17 scales, and per-branch
+    Fitch parsimony counts shrunk towards that.  On loci that follow the input tree the two starts end at the
+    same optimum.  With input branch lengths that are off by a factor exp(N(0, 2)) each -- same topology, same data -- the shape
+    start parks branches at saturating lengths where the gradient vanishes and ends hundreds of log-units lower; the counts
+    do not care what the input lengths were: same optimum as with the right tree, in fewer iterations than the shape start."""
+    engine = _engine()
+    from tapir_amd import nexus, synth
+    L, n, nt = 24, 400, 24
+    d = synth.simulate(L, n, nt, 8)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    pi = nexus.base_frequencies_from_histogram(engine.state_histogram(st, d["locus_offsets"]))
+    rng = np.random.default_rng(3)
+    right = np.asarray(pin["blen"], dtype=np.float64)
+    wrong = right * np.exp(2.0 * rng.standard_normal(len(right)))
+    res = {}
+    for tree, blen in (("right", right), ("wrong", wrong)):
+        plan = engine.Plan(nt, pin["parent"], blen, pin["leaf"], d["locus_offsets"], pi, np.ones((L, 6)), pin["T"], [1], [[0, 1]],
+                           correction=pin["correction"])
+        for start in ("grid", "shrunk"):
+            monkeypatch.setenv("TPHIP_S1_START", start)
+            res[tree, start] = plan.stage1_fit(st)
+        plan.close()
+    monkeypatch.delenv("TPHIP_S1_START")
+    ref = res["right", "grid"]
+    a = res["right", "shrunk"]
+    assert np.abs(a["lnl"][:, 0] - ref["lnl"][:, 0]).max() < 1e-3
+    assert (np.abs(a["exch"] - ref["exch"]) / ref["exch"]).max() < 1e-3
+    b, g = res["wrong", "shrunk"], res["wrong", "grid"]
+    assert np.abs(b["lnl"][:, 0] - ref["lnl"][:, 0]).max() < 1e-3            # the optimum does not depend on the input lengths
+    assert (np.abs(b["exch"] - ref["exch"]) / ref["exch"]).max() < 2e-3
+    assert ((b["lnl"][:, 0] - g["lnl"][:, 0]) > 1.0).sum() >= L // 2          # ... which the shape start misses by a lot
+    assert (b["lnl"][:, 0] - g["lnl"][:, 0]).min() > -1e-3
+    assert b["grm_iters"].mean() < g["grm_iters"].mean()
+
+
 def test_stage1_fullsize_properties():
     """Stage 1 at the C3 shape (50 000 columns x 64 taxa per locus; 4 loci), through size-independent properties:
     the general model's point is stationary (gradient kernel at the returned point), nesting holds (no constrained
