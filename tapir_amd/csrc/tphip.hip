@@ -460,7 +460,12 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
         if (p->site_mixed) {
             int per3 = 0;
             const size_t lds3 = (kMixedLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);
+            const int64_t simds = 4 * (int64_t)prop.multiProcessorCount;
+            const double est_rounds = (double)ncols * (p->start_rule == TPHIP_START_REFERENCE ? 2.2 : 1.4) / (double)(kSiteBlock * simds);
             if (lds3 > 160 * 1024 || site_rate_kernel_occupancy(kMixedVariant + (p->nwords <= 2 ? 2 : 8), lds3, &per3) != hipSuccess || per3 < 1) p->site_mixed = 0;
+            // a batch that wants two waves per SIMD on a tree whose tables leave room for six per CU (64 taxa: 23.3 KB of LDS
+            // per wave) stays with the slices: 1900 loci x 1000 x 64, 3.36 ms in slices, 4.10 with 1024 mixed waves
+            else if (est_rounds >= 28.0 && per3 < 8 && !getenv("TPHIP_SITE_MIXED")) p->site_mixed = 0;
             else {
                 p->site_persistent = 0;
                 // One wave per SIMD or two?  A second wave on a SIMD adds half again to its throughput (C2: 15.2 us per round of
@@ -469,10 +474,9 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
                 // (~17 rounds per SIMD): 1024 waves 0.348 ms, 2048 waves 0.391, 1152 waves 0.422 (SIMDs shared unevenly); the
                 // estimate puts the crossover near 28 rounds per SIMD.  Rounds are estimated from the column count: ~0.6 of
                 // the columns need the optimiser, 3.7 evaluations each from HyPhy's start value, 2.4 from the parsimony start.
-                const int64_t simds = 4 * (int64_t)prop.multiProcessorCount;
-                const double est_rounds = (double)ncols * (p->start_rule == TPHIP_START_REFERENCE ? 2.2 : 1.4) / (double)(kSiteBlock * simds);
-                const int64_t want = (est_rounds < 28.0) ? std::min<int64_t>(simds, (int64_t)per3 * prop.multiProcessorCount)
-                                                         : (int64_t)std::min(per3, 8) * prop.multiProcessorCount;
+                // (two per SIMD only if all eight fit a CU: 64-taxon trees hold six, and SIMDs shared unevenly are the worst case)
+                const int64_t want = (est_rounds < 28.0 || per3 < 8) ? std::min<int64_t>(simds, (int64_t)per3 * prop.multiProcessorCount)
+                                                                     : 8 * (int64_t)prop.multiProcessorCount;
                 p->site_waves = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, (ncols + kSiteBlock - 1) / kSiteBlock));
             }
         }
