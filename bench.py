@@ -346,7 +346,9 @@ def real_data_workload(args):
     """--workload R1: a real-data-shaped batch.  The synthetic configs repeat almost no column (5 % random gaps), so the
     one-fit-per-unique-pattern machinery (HyPhy: GetDataInfo(dupInfo...), alreadyDone[siteMap], models_and_rates.bf:1033-1044;
     here csrc/pattern_kernels.hpp) is idle in them.  R1 = bootstrap resamples of the reference's bundled locus
-    (tests/golden/chr1_918.nex, 5 taxa x 226 columns, 57 patterns) on its tree, 512 loci x 2048 columns = 2^20 columns, with
+    (tests/golden/chr1_918.nex, 5 taxa x 226 columns, 57 patterns) on its tree, 1536 loci x 2048 columns = 3.1e6 columns (at the 2^20
+    columns from which the automatic mode engages, the batch still runs in a latency-bound small-batch mode where 36 x fewer
+    columns to fit are worth 0.04 ms and the four extra launches cost 0.065), with
     the PhyDesign parameters of the known-answer file; the line carries `dedup` = the same pass with de-duplication off and
     automatic (bit-identical outputs are required)."""
     import torch
@@ -359,7 +361,7 @@ def real_data_workload(args):
     kat = json.load(open(os.path.join(g, "chr1_918_phydesign_rates.json")))
     pi = np.array(kat["freqs_ACGT"])
     exch = np.array([kat[k] for k in ("AC", "AG", "AT", "CG", "CT", "GT")])
-    L, S = args.loci or 512, 2048
+    L, S = args.loci or 1536, 2048
     rng = np.random.default_rng(20261004)
     st = np.ascontiguousarray(np.concatenate([states[:, rng.integers(0, states.shape[1], S)] for _ in range(L)], axis=1))
     uniq = np.mean([len({st[:, l * S + c].tobytes() for c in range(S)}) for l in range(min(L, 32))]) / S

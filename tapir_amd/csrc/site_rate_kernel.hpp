@@ -607,11 +607,19 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
     int64_t g0, g1, lo_l;
     if (P.persistent) {
         const int64_t total = P.work_prefix[P.nloci];
+        // MIXED: one wave per SIMD or two is decided here, where the length of the work list is known (after classification
+        // and de-duplication): a short list ends with the wave that carries its slowest column, and a second wave on that
+        // wave's SIMD makes each of its rounds longer (tphip.hip, where the threshold is set)
+        unsigned nshares = gridDim.x;
+        if constexpr (MIXED) {
+            if (total < P.mixed_switch_cols && nshares > (unsigned)P.mixed_few_waves) nshares = (unsigned)P.mixed_few_waves;
+            if (blockIdx.x >= nshares) return;
+        }
         // Share boundaries: with more shares than resident waves the first round (one share per resident wave) gets
         // `first_fraction` of the work and the later, smaller shares are what the dispatcher balances the waves'
         // finishing times with (equal shares when first_fraction = first_round / gridDim.x).
         auto boundary = [&](unsigned b) -> int64_t {
-            const unsigned R = (unsigned)P.first_round, N = gridDim.x;
+            const unsigned R = (unsigned)P.first_round, N = nshares;
             if (R >= N) return (int64_t)b * total / N;
             const double f = (b <= R) ? P.first_fraction * (double)b / (double)R
                                       : P.first_fraction + (1.0 - P.first_fraction) * (double)(b - R) / (double)(N - R);

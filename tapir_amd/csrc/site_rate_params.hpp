@@ -65,6 +65,8 @@ struct SiteParams {
                                    // (the mixed-loci variants are launched with 1 and equal shares)
     int32_t first_round;           // persistent: the first `first_round` workgroups (one per resident wave) share
     double first_fraction;         //   this fraction of the work equally, the others the rest (see site_rate_kernel)
+    int32_t mixed_few_waves;       // mixed-loci mode: with fewer than mixed_switch_cols columns on the work list only this many
+    int64_t mixed_switch_cols;     //   workgroups take shares (one wave per SIMD), the others leave at once
     int32_t ncat;                  // > 1: discrete rate mixture on top of the site rate (tphip_plan_desc.ncat)
     const double* cat;             // [2 * ncat]: category rate multipliers, then log weights
     double* rate;

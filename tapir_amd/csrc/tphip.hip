@@ -470,17 +470,22 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
                 p->site_persistent = 0;
                 // One wave per SIMD or two?  A second wave on a SIMD adds half again to its throughput (C2: 15.2 us per round of
                 // evaluations alone, 19.8 us each for two) but lengthens every round of the wave that carries the slowest column
-                // (22 evaluations on C2 when the average column takes 3.7), and the launch ends with that wave.  Measured on C2
-                // (~17 rounds per SIMD): 1024 waves 0.348 ms, 2048 waves 0.391, 1152 waves 0.422 (SIMDs shared unevenly); the
-                // estimate puts the crossover near 28 rounds per SIMD.  Rounds are estimated from the column count: ~0.6 of
-                // the columns need the optimiser, 3.7 evaluations each from HyPhy's start value, 2.4 from the parsimony start.
-                // (two per SIMD only if all eight fit a CU: 64-taxon trees hold six, and SIMDs shared unevenly are the worst case)
-                const int64_t want = (est_rounds < 28.0 || per3 < 8) ? std::min<int64_t>(simds, (int64_t)per3 * prop.multiProcessorCount)
-                                                                     : 8 * (int64_t)prop.multiProcessorCount;
+                // (22 evaluations on C2 when the average column takes 3.7), and the launch ends with that wave.  Measured, one
+                // per SIMD / two: C2 (17 rounds of evaluations per SIMD) 0.348 / 0.391 ms, two C2s (34 rounds) 0.789 / 0.508,
+                // 300 loci x 1000 x 64 (8 rounds) 0.757 / 0.932, the resampled 5-taxon locus of bench.py --workload R1 (18 rounds;
+                // 1.5 after de-duplication) 0.150 / 0.165 and 0.099 / 0.138; 1152 waves on C2 0.422 (SIMDs shared unevenly).
+                // The grid is two per SIMD where eight waves fit a CU (64-taxon trees hold six: one per SIMD, and the batches
+                // that want two stay with the slices, above); the kernel uses half of it when the work list -- known on the
+                // device only, after classification and de-duplication -- is shorter than ~24 rounds per SIMD at 3.7
+                // evaluations per column from HyPhy's start value, 2.4 from the parsimony start.
+                const int64_t want = (per3 < 8) ? std::min<int64_t>(simds, (int64_t)per3 * prop.multiProcessorCount)
+                                                : 8 * (int64_t)prop.multiProcessorCount;
+                p->mixed_few_waves = (int32_t)std::min<int64_t>(simds, want);
+                p->mixed_switch_cols = (int64_t)(24.0 * (double)(kSiteBlock * simds) / (p->start_rule == TPHIP_START_REFERENCE ? 3.7 : 2.4));
                 p->site_waves = (int32_t)std::max<int64_t>(1, std::min<int64_t>(want, (ncols + kSiteBlock - 1) / kSiteBlock));
             }
         }
-        if (const char* e2 = getenv("TPHIP_SITE_WAVES")) { long v = atol(e2); if (v >= 1) p->site_waves = (int32_t)v; }  // tuning knob
+        if (const char* e2 = getenv("TPHIP_SITE_WAVES")) { long v = atol(e2); if (v >= 1) { p->site_waves = (int32_t)v; p->mixed_switch_cols = 0; } }  // tuning knob
         // Share sizes of the persistent grid.  Equal shares (one per resident wave) are equal column counts, not equal
         // work: loci differ in evaluations per column, and with 5-7 resident waves per CU (deep LDS stacks) a wave that
         // shares its SIMD runs slower than one that does not.  So the resident waves' first shares take 80-90 % of the
@@ -691,6 +696,7 @@ static int launch_site_rates(tphip_plan* p, const uint8_t* d_states, double* d_r
     S.spill = spill ? (double*)((char*)ws + p->ws_spill) : nullptr;
     S.persistent = (p->site_persistent || p->site_mixed) ? 1 : 0;
     S.first_round = p->site_waves;
+    S.mixed_few_waves = p->mixed_few_waves; S.mixed_switch_cols = p->mixed_switch_cols;
     S.first_fraction = (p->site_first_fraction > 0.0) ? p->site_first_fraction : 1.0 / (double)p->site_grid_mult;
     S.ncat = p->ncat; S.cat = p->d_cat.p;
     // profiling brackets exactly the dominant kernel, so the figure matches rocprofv3's per-kernel average
@@ -1361,7 +1367,7 @@ int tphip_eval_columns_dev(tphip_plan* p, const uint8_t* d_s, const double* d_u,
     E.S.locus_offsets = p->d_offsets.p; E.S.chunk_locus = p->d_site_chunk_locus.p; E.S.chunk_index = p->d_site_chunk_index.p;
     E.S.chunk_cols = p->site_chunk_cols;
     E.S.packed = nullptr; E.S.nwords = 0;
-    E.S.work_cols = nullptr; E.S.work_cols2 = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
+    E.S.work_cols = nullptr; E.S.work_cols2 = nullptr; E.S.work_count = nullptr; E.S.work_prefix = nullptr; E.S.nloci = p->nloci; E.S.persistent = 0; E.S.first_round = 0; E.S.mixed_few_waves = 0; E.S.mixed_switch_cols = 0; E.S.first_fraction = 1.0; E.S.ncat = p->ncat; E.S.cat = p->d_cat.p; E.S.rate = nullptr; E.S.subst = nullptr; E.S.lnl = nullptr;
     E.S.flag = nullptr; E.S.eval_counter = nullptr; E.S.spill = nullptr; E.S.lds_depth = p->prog.stack_depth;
     E.u = d_u; E.f = d_f; E.g = d_g; E.h = d_h;
     const size_t lds = (kSiteLdsHeader + (size_t)p->prog.stack_depth * 12 * kSiteBlock) * sizeof(double);

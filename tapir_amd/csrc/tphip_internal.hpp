@@ -147,6 +147,8 @@ struct tphip_plan {
     int32_t num_cus = 256;
     int32_t site_waves = 0;  // persistent grid of site_rate_kernel = resident waves on the device
     int32_t site_persistent = 1;
+    int32_t mixed_few_waves = 0;   // mixed-loci mode: workgroups that take shares when the work list is short (SiteParams)
+    int64_t mixed_switch_cols = 0;
     int32_t site_mixed = 0;        // small batches: waves carry columns of several loci (site_rate_kernel<NW, false, true>)
     int32_t site_grid_mult = 1;   // persistent grid = resident waves x this (see plan creation)
     int32_t site_lds_depth = 0;   // parked partials kept in LDS by site_rate_kernel (< stack depth: SPILL variant)
