@@ -310,9 +310,31 @@ __global__ __launch_bounds__(kGrad2Block, TPHIP_GRAD2_MIN_WAVES) void locus_grad
             double u[4] = {0.0, 0.0, 0.0, 0.0};
             int rsp = 0;
             g2_i4 ra = rops[0], rb = rops[1];
+            // the messages of a record's internal children are requested one record ahead: the tape round trip (L2 for the
+            // last few slots written, the memory-side cache or HBM for the rest) then runs under the previous record's arithmetic
+            double nA[4] = {0.0, 0.0, 0.0, 0.0}, nB[4] = {0.0, 0.0, 0.0, 0.0};
+            auto request = [&](const g2_i4& r4) {
+                if (!(r4.x & G2_A_TIP)) {
+                    const g2_gptr slot = tape + (size_t)r4.z * 4 * kGrad2Block;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) nA[i] = slot[i * kGrad2Block];
+                }
+                if (!(r4.x & G2_B_TIP)) {
+                    const g2_gptr slot = tape + (size_t)r4.w * 4 * kGrad2Block;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) nB[i] = slot[i * kGrad2Block];
+                }
+            };
+            request(ra);
             for (int ir = 0; ir < G.nrops; ++ir) {
                 const g2_i4 a4 = ra, b4 = rb;
-                if (ir + 1 < G.nrops) { ra = rops[2 * ir + 2]; rb = rops[2 * ir + 3]; }
+                double pA[4], pB[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { pA[i] = nA[i]; pB[i] = nB[i]; }
+                if (ir + 1 < G.nrops) {
+                    ra = rops[2 * ir + 2]; rb = rops[2 * ir + 3];
+                    request(ra);
+                }
                 const int flags = a4.x;
                 if (flags & G2_POP_U) {
                     --rsp;
@@ -326,17 +348,15 @@ __global__ __launch_bounds__(kGrad2Block, TPHIP_GRAD2_MIN_WAVES) void locus_grad
                     cdA = (msk[(size_t)(b4.x & 0xffff) * kGrad2Block + tid] >> (b4.x >> 16)) & 15u;
                     tip_msg(a4.z, cdA, mA);
                 } else {
-                    const g2_gptr slot = tape + (size_t)a4.z * 4 * kGrad2Block;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) mA[i] = slot[i * kGrad2Block];
+                    for (int i = 0; i < 4; ++i) mA[i] = pA[i];   // requested while the previous record was worked on
                 }
                 if (flags & G2_B_TIP) {
                     cdB = (msk[(size_t)(b4.y & 0xffff) * kGrad2Block + tid] >> (b4.y >> 16)) & 15u;
                     tip_msg(a4.w, cdB, mB);
                 } else {
-                    const g2_gptr slot = tape + (size_t)a4.w * 4 * kGrad2Block;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) mB[i] = slot[i * kGrad2Block];
+                    for (int i = 0; i < 4; ++i) mB[i] = pB[i];
                 }
                 double a[4];
                 if (flags & G2_IS_ROOT) {
