@@ -906,6 +906,17 @@ __global__ __launch_bounds__(kSiteBlock, TPHIP_SITE_MIN_WAVES) void site_rate_ke
                     } else {
                         step = uphill ? kStepMax : -kStepMax;
                     }
+                    // Weakly curved concave point with a previous concave point nearby: Halley's step with the third derivative
+                    // from the last two curvatures (same rule as the oracle, which says why): on the approach to a flat maximum
+                    // at a large rate Newton-type steps converge linearly, and in a small batch the launch waits for that lane.
+                    if (have_prev && h < 0.0 && h_prev < 0.0 && !regular_here && fabs(u - u_prev) < kHalleySpan) {
+                        const double f3h = (h - h_prev) / (u - u_prev);
+                        const double den = h - 0.5 * g * f3h / h;
+                        if (den < 0.0) {
+                            const double sh = -g / den;
+                            if (fabs(sh) <= kStepMax && (sh > 0.0) == (g > 0.0)) step = sh;
+                        }
+                    }
                     if (!(step <= kStepMax)) step = kStepMax;
                     if (step < -kStepMax) step = -kStepMax;
                     // Plateau stride (same rule as the oracle): still uphill at a rate of 20 or more with nothing known

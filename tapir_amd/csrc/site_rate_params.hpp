@@ -21,6 +21,7 @@ constexpr double kHermiteT2D3 = 1.5e-8;  // step^2 * |distance of the far point|
 constexpr double kHermiteGuard = 0.005;  // the quartic's higher-order terms at the step, relative to |h|
 constexpr double kHermiteRegular = 0.25; // curvature |h| from which the two exits apply (below: iterate until the step is below 1e-6)
 constexpr double kHermiteNoise = 5.3e-5; // 30 * (8 * 2.2e-16) / 1e-9: rounding of the two values vs curvature (site_rate_kernel.hpp)
+constexpr double kHalleySpan = 1.0;      // the two curvatures behind the Halley step of a weakly curved point lie this close
 constexpr double kStepTolFirst = 1e-6;  // ... except at the first evaluation (no second point yet)
 constexpr int kMaxIt = 100;
 constexpr double kFlatEps = 1e-10;  // |g| and |h| below this: log L flat to fp64 resolution -> saturated
