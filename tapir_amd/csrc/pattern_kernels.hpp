@@ -177,7 +177,7 @@ __device__ __forceinline__ unsigned long long dedup_key(uint64_t h) { return h =
 
 constexpr int64_t kDedupEstimatePrefix = 16384;   // columns of a locus the estimate looks at (0.17 -> 0.02 ms on C3)
 // Batches below this many columns are not de-duplicated in automatic mode: they run in the latency-bound small-batch
-// mode of site_rate_kernel (one wave per locus slice), where fewer columns hardly shorten the kernel and the four extra
+// modes of site_rate_kernel (a launch lasts as long as its slowest wave), where fewer columns hardly shorten the kernel and the four extra
 // launches cost more than they save (C2, 5e5 columns: 0.50 -> 0.53 ms per step with the machinery idling).
 constexpr int64_t kDedupAutoMinColumns = 1 << 20;
 

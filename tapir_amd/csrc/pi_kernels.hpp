@@ -227,7 +227,7 @@ __device__ __forceinline__ void classify_finish(const ClassifyParams& P, const L
         // the extra logarithm costs more than the saved evaluations (C2, 16 taxa: +4 % time with it; C3 -2 %, C5 -4 %)
         P.subst[col] = (P.ntaxa >= kFirstStepMinTaxa) ? (double)c.changes * P.start_scale : 0.0;
         // ... and in the `lnl` slot (also overwritten with the answer) whether the column is likely to need many evaluations:
-        // a parsimony count of 30 % or more of the resolved taxa.  Small batches run one wave per locus slice and last as
+        // a parsimony count of 30 % or more of the resolved taxa.  Small batches (slice and mixed-loci modes of site_rate_kernel) last as
         // long as their slowest wave; a slow column (one in a hundred needs 9-17 evaluations from siteRate = 1, all of them
         // in this class: tools/debug note in DESIGN section 8 r3) taken late keeps its wave alive alone, so those waves
         // take the marked columns first (site_rate_kernel, small-batch mode).  The order changes no column's result.

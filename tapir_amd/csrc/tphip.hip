@@ -445,8 +445,8 @@ int tphip_plan_create(const tphip_plan_desc* d_in, tphip_plan** out) {
         }
         if (const char* env = getenv("TPHIP_LIK_NSPLIT")) p->lik_nsplit_forced = std::max(1, atoi(env));
         if (const char* fb = getenv("TPHIP_FORCE_BYTE_PATH")) p->force_byte_path = (fb[0] == '1');
-        // Small batches (an equal share would be under ~1000 columns) run one workgroup per locus-aligned
-        // slice instead: cutting a small locus in two doubles its prologue and drain (measured on C2).
+        // Small batches (an equal share would be under ~1000 columns) leave the persistent grid: the mixed-loci mode below,
+        // or one workgroup per locus-aligned slice (cutting a small locus in two doubles its prologue and drain: measured on C2).
         p->site_persistent = (ncols / p->site_waves >= 1000) ? 1 : 0;
         if (const char* e3 = getenv("TPHIP_SITE_PERSISTENT")) p->site_persistent = (e3[0] == '1');
         if (!p->site_persistent && p->site_lds_depth < p->prog.stack_depth) {   // the scratch rows are per persistent wave
