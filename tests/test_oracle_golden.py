@@ -167,6 +167,33 @@ def test_start_modes_agree_on_unimodal_columns_and_differ_rarely(oracle):
     assert differ <= 5, differ                 # 20 000 columns: expect ~1
 
 
+def test_optimiser_tail_on_small_trees(oracle):
+    """Evaluations per column from HyPhy's start value on 5-taxon columns (the shape of the reference's bundled locus), column
+    by column: a small batch lasts as long as its slowest column, so the TAIL of this distribution is a performance contract
+    of the optimiser the kernel shares with the oracle.  With the Halley step at weakly curved points the slowest of these
+    1525 optimised columns takes 15 evaluations and 3 take 14 or more (without it: 27 and 24; mean 4.36 instead of 4.18)."""
+    from tapir_amd import synth
+    d = synth.simulate(8, 500, 5, 3)
+    pin = synth.plan_inputs(d["root"], d["names"])
+    st = d["states"].numpy()
+    off = d["locus_offsets"]
+    ev = []
+    for l in range(8):
+        sub = st[:, off[l]:off[l + 1]]
+        whole = oracle.site_rates(np.ascontiguousarray(sub), pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l])
+        total = 0
+        for i in range(sub.shape[1]):
+            r = oracle.site_rates(np.ascontiguousarray(sub[:, i:i + 1]), pin["parent"], pin["blen"], pin["leaf"], d["pi"][l], d["exch"][l])
+            total += r["nevals"]
+            if r["flag"][0] in (0, 2):
+                ev.append(r["nevals"])
+            assert r["flag"][0] == whole["flag"][i] and r["rate"][0] == whole["rate"][i]   # a column does not depend on its neighbours
+        assert total == whole["nevals"]
+    ev = np.array(ev)
+    assert len(ev) > 1400
+    assert ev.max() <= 20 and (ev >= 14).sum() <= 10 and ev.mean() < 4.25, (ev.max(), (ev >= 14).sum(), ev.mean())
+
+
 def test_informative_mask_goldens(oracle, golden_dir):
     """chr1_918-test-cutoff-values.npy (threshold 3) and the 4-column toy alignment of
     test_compute.py:99-103 (expected [nan, nan, 1, 1])."""
